@@ -1,0 +1,213 @@
+/*
+ * sparsify_hip.h - C ABI of libsparsify_hip.so, the MI355X (gfx950) kernels behind the
+ * CLIP-on-COCO training step of noostale/sparsify-clip.
+ *
+ * The reference has no FFI: its hot path reaches ATen/cuBLAS/cuDNN through PyTorch.  Each entry
+ * point below therefore cites the reference line whose arithmetic it replaces
+ * (/root/reference/sparsify_clip.py unless noted; encoder internals live in the un-vendored
+ * open-clip-torch==2.29.0, reference environment.yml:191, call sites :768-769).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer (inputs, outputs, workspace) is owned by the caller
+ *     and is DEVICE memory unless a parameter is documented as host;
+ *   - row-major, leading dimension in ELEMENTS passed explicitly where a matrix is not dense;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising; scalar results are written to device memory;
+ *   - return 0 on success, negative SC_ERR_* for host-side argument errors, positive = hipError_t;
+ *     sc_last_error() returns thread-local text; nothing is printed, nothing throws;
+ *   - reductions use fixed-order partials (no float atomics): results are bit-stable run to run.
+ */
+#ifndef SPARSIFY_HIP_H
+#define SPARSIFY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+
+enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_SHAPE = -2, SC_ERR_DTYPE = -3, SC_ERR_ALIGN = -4,
+       SC_ERR_WORKSPACE = -5, SC_ERR_NO_DEVICE = -6 };
+enum { SC_F32 = 0, SC_BF16 = 1 };
+
+const char* sc_last_error(void);
+int sc_abi_version(void);
+/* size in bytes of the ABI structs, for binding self-checks: 0 = sc_block_desc, 1 = sc_gemm_epilogue */
+size_t sc_abi_sizeof(int which);
+int sc_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  (replaces every torch `linear` / `mm` / `conv2d(stride=kernel)` on the path, SURVEY 2.3 K1,K4,K6-K8,K10,K12)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sc_gemm_epilogue {
+    /* out = act( alpha*acc + bias[n] ) * gelu'(dgelu_pre[m][n]) + resid[m][n] + beta*out_old ; each stage optional */
+    float alpha, beta;
+    const float* bias;        /* [N] fp32 or NULL */
+    void* pre_out;            /* [M,N] activation dtype (fp32 in sc_gemm_f32, bf16 in sc_gemm_bf16_nt): value before the activation, or NULL */
+    int32_t act;              /* 0 none, 1 exact erf GELU (nn.GELU) */
+    int32_t resid_dtype;      /* dtype of resid (SC_F32 or SC_BF16) */
+    const void* resid;        /* [M,N] added after the activation, or NULL */
+    const void* dgelu_pre;    /* [M,N] activation dtype: multiply by GELU'(this), or NULL (backward of K7) */
+    int64_t ld_aux;           /* leading dimension of pre_out / resid / dgelu_pre */
+} sc_gemm_epilogue;
+
+/* fp32 MFMA GEMM, any operand orientation: C[M,N] = op(A) * op(B).
+ * trans_a == 0: A is [M,K] (lda >= K); trans_a == 1: A is [K,M] (lda >= M).
+ * trans_b == 0: B is [K,N] (ldb >= N); trans_b == 1: B is [N,K] (ldb >= K)  (torch linear weight layout). */
+int sc_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
+                const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc,
+                const sc_gemm_epilogue* epi /* NULL = plain product */, void* stream);
+
+/* bf16 MFMA GEMM, fp32 accumulate.  "NT": C[M,N] = A[M,K] * B[N,K]^T, both K-contiguous
+ * (activation x torch-layout weight).  K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
+ * out_dtype selects a bf16 or fp32 C. */
+int sc_gemm_bf16_nt(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb,
+                    void* c, int64_t ldc, int out_dtype, const sc_gemm_epilogue* epi, void* stream);
+/* "TN": C[M,N] (fp32) = alpha * sum_r A[r][m] * B[r][n] + beta*C, A is [R,M], B is [R,N] (weight gradients:
+ * dW = dY^T X).  M % 8 == 0, N % 8 == 0.  The contraction is split over workgroups when M*N is small; the
+ * fp32 partial slabs go to ws (sc_gemm_bf16_tn_workspace_bytes) and are summed in a fixed order. */
+size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t r);
+int sc_gemm_bf16_tn(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb,
+                    float* c, int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss head on [B,E] fp32 embeddings  (sparsify_clip.py:110-187, :334-355, :772-773, :804)
+ * All *_fwd_bwd calls write the scalar loss to loss_out[0] (device) and the gradient of
+ * (grad_scale * loss) to the d_* buffers (overwriting).  d_* may be NULL to skip the backward.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sc_loss_workspace_bytes(int64_t b, int64_t e);
+
+/* contrastive_loss(image_embeds, text_embeds, temperature)  :110-132.  d_temp (device float, may be NULL)
+ * receives d loss / d temperature for the learnable-temperature configuration (:716-717). */
+int sc_contrastive_fwd_bwd(const float* img, const float* txt, int64_t b, int64_t e, float temperature,
+                           float grad_scale, float* loss_out, float* d_img, float* d_txt, float* d_temp,
+                           void* ws, size_t ws_bytes, void* stream);
+/* lunif_loss(x, t)  :159-164  (log-mean-exp over all i<j of -t*||xi-xj||^2, via Gram + fused exp). */
+int sc_lunif_fwd_bwd(const float* x, int64_t b, int64_t e, float t, float grad_scale, float* loss_out,
+                     float* d_x, void* ws, size_t ws_bytes, void* stream);
+/* lalign_loss(x, y, alpha)  :186-187 */
+int sc_lalign_fwd_bwd(const float* x, const float* y, int64_t b, int64_t e, float alpha, float grad_scale,
+                      float* loss_out, float* d_x, float* d_y, void* ws, size_t ws_bytes, void* stream);
+/* sparsify_loss(x)  :166-176 */
+int sc_sparsify_fwd_bwd(const float* x, int64_t b, int64_t e, float grad_scale, float* loss_out, float* d_x,
+                        void* ws, size_t ws_bytes, void* stream);
+/* Row L2 normalisation y = x / max(||x||, eps); eps = 0 reproduces :772-773 (no clamp), eps = 1e-12 F.normalize (:804).
+ * inv_norm [B] is saved for the backward. */
+int sc_l2norm_fwd(const float* x, int64_t b, int64_t e, float eps, float* y, float* inv_norm, void* stream);
+int sc_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, int64_t b, int64_t e, float* dx, void* stream);
+/* compute_centroids_only + F.normalize  (:334-355, :804): c = normalize((a+b)/2). */
+int sc_centroid_fwd(const float* a, const float* b_, int64_t b, int64_t e, float* c, float* inv_norm, void* stream);
+/* backward of the above: given dc, ACCUMULATES into d_a and d_b (d += ...). */
+int sc_centroid_bwd(const float* c, const float* inv_norm, const float* dc, int64_t b, int64_t e,
+                    float* d_a, float* d_b, void* stream);
+/* out[i] += alpha * in[i]  (fp32), n elements; used to combine loss-term gradients. */
+int sc_axpy_f32(int64_t n, float alpha, const float* x, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Eval: retrieval ranks on device (sparsify_clip.py:357-416) without sort/.tolist().
+ * score is [N,N] fp32 (rows = text queries, :628).  rank_fwd[i] = #{j : s[i][j] > s[i][i]} (+ ties with j < i),
+ * rank_bwd[j] likewise down column j.  top1_fwd/top1_bwd = argmax (first occurrence), int32.
+ * ---------------------------------------------------------------------------------------------- */
+int sc_retrieval_ranks(const float* score, int64_t n, int32_t* rank_fwd, int32_t* rank_bwd,
+                       int32_t* top1_fwd, int32_t* top1_bwd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder building blocks (open_clip ViT / text transformer)
+ * `dtype` is the activation/GEMM-operand dtype (SC_BF16 or SC_F32); the residual stream, LayerNorm
+ * statistics, biases, LayerNorm affine parameters and all parameter gradients are fp32.
+ * ---------------------------------------------------------------------------------------------- */
+/* LayerNorm(eps 1e-5, affine) over rows of a fp32 [rows,width] matrix -> y (dtype).  K3 */
+int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, const float* gamma, const float* beta,
+                     void* y, int dtype, float* mean, float* rstd, void* stream);
+/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta accumulate (+=) when accumulate != 0. ws >= 2*256*width floats */
+int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, int64_t rows, int64_t width, const float* dres, float* dx,
+                     void* dx_cast /* optional copy of dx in `dtype`, the next GEMM's operand */,
+                     float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* softmax(QK^T/sqrt(64) [+causal mask]) V for packed qkv [B*S, 3*W] (nn.MultiheadAttention in_proj layout). K5 */
+int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads,
+                     int causal, void* stream);
+int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq,
+                     int64_t width, int64_t heads, int causal, void* stream);
+/* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 256*n floats */
+int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate,
+              void* ws, size_t ws_bytes, void* stream);
+/* K1: images fp32 [B,3,R,R] -> patches [B*g*g, kpad] (dtype), g = R/P, column (c,ky,kx); columns >= 3*P*P zero */
+int sc_im2col(const float* images, int64_t batch, int64_t res, int64_t patch, int64_t kpad, void* out, int dtype, void* stream);
+/* K2: x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patch_out[b*g*g+p,:] + pos[1+p]  -> fp32 [B*S, W] */
+int sc_vit_tokens_fwd(const void* patch_out, int dtype, const float* cls, const float* pos, int64_t batch, int64_t seq,
+                      int64_t width, float* x, void* stream);
+/* backward: d_patch_out (dtype), d_cls [W] and d_pos [S,W] (+= when accumulate) from dx fp32 [B*S,W] */
+int sc_vit_tokens_bwd(const float* dx, int64_t batch, int64_t seq, int64_t width, void* d_patch_out, int dtype,
+                      float* d_cls, float* d_pos, int accumulate, void* stream);
+/* K9: x[b,s,:] = tok_emb[tokens[b,s]] + pos[s] -> fp32 [B*S,W]; tokens int64 */
+int sc_text_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos, int64_t batch, int64_t seq,
+                      int64_t width, int64_t vocab, float* x, void* stream);
+/* backward: d_pos [S,W] (+=) and the token-embedding scatter-add.  `order` [n_sorted] lists flat positions b*S+s sorted by
+ * token id (stable), `sorted_tokens` = tokens[order]; each d_tok_emb [vocab,W] row receives the sum of its run in that fixed
+ * order (no atomics).  Positions whose dx row is known to be zero (after EOT under the causal mask) may be left out. */
+int sc_text_embed_bwd(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted,
+                      int64_t batch, int64_t seq, int64_t width, int64_t vocab, float* d_tok_emb, float* d_pos,
+                      int accumulate, void* stream);
+/* eot[b] = argmax_s tokens[b,s] (first occurrence)  (text_global_pool 'argmax') */
+int sc_argmax_tokens(const int64_t* tokens, int64_t batch, int64_t seq, int32_t* eot, void* stream);
+/* K10 gather: out[b,:] = x[b*seq + (idx ? idx[b] : 0), :]  (fp32) ; scatter is its adjoint into a ZEROED dx */
+int sc_pool_gather(const float* x, const int32_t* idx, int64_t batch, int64_t seq, int64_t width, float* out, void* stream);
+int sc_pool_scatter(const float* d_out, const int32_t* idx, int64_t batch, int64_t seq, int64_t width, float* dx, void* stream);
+/* dst(bf16)[i] = src(fp32)[i] */
+int sc_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst(bf16) [cols,rows] = transpose(src fp32 [rows,cols]) */
+int sc_transpose_cast_bf16(const float* src, int64_t rows, int64_t cols, void* dst, void* stream);
+
+/* One pre-LN residual attention block, forward and backward (K3-K8).  All pointers device. */
+typedef struct sc_block_desc {
+    int64_t batch, seq, width, heads, mlp_width;
+    int32_t dtype;      /* SC_BF16 or SC_F32 */
+    int32_t causal;
+    /* parameters, fp32 master (LN affine, biases always read from here) */
+    const float *ln1_g, *ln1_b, *b_qkv, *b_o, *ln2_g, *ln2_b, *b_fc1, *b_fc2;
+    /* GEMM weights in `dtype`, torch layout [out,in]; for SC_F32 these are the fp32 masters themselves */
+    const void *w_qkv, *w_o, *w_fc1, *w_fc2;
+    /* transposed [in,out] copies in `dtype` (SC_BF16 only, used by the backward); NULL for SC_F32 */
+    const void *wt_qkv, *wt_o, *wt_fc1, *wt_fc2;
+    /* saved activations (written by fwd, read by bwd) */
+    const float* x_in;  /* [rows,W] fp32 residual stream entering the block */
+    float* x_mid;       /* [rows,W] fp32 after attention residual */
+    float* x_out;       /* [rows,W] fp32 block output */
+    void *ln1_out, *qkv, *attn_out, *ln2_out, *h_pre, *h_act;   /* dtype */
+    float *ln1_mean, *ln1_rstd, *ln2_mean, *ln2_rstd;           /* [rows] */
+    /* backward: gradients of parameters, fp32, accumulated (+=) when accumulate != 0 */
+    float *g_ln1_g, *g_ln1_b, *g_w_qkv, *g_b_qkv, *g_w_o, *g_b_o, *g_ln2_g, *g_ln2_b, *g_w_fc1, *g_b_fc1, *g_w_fc2, *g_b_fc2;
+    int32_t accumulate;
+    int32_t _pad;
+    /* backward scratch (dtype unless noted): d_h [rows,mlp], d_ln [rows,W], d_qkv [rows,3W], d_attn [rows,W],
+     * d_res_t [rows,W] (GEMM-operand copy of the fp32 residual gradients; unused for SC_F32) */
+    void *d_h, *d_ln, *d_qkv, *d_attn, *d_res_t;
+    float* dx_mid;      /* [rows,W] fp32 scratch */
+    void* ws;           /* reduction workspace */
+    size_t ws_bytes;
+} sc_block_desc;
+
+size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype);
+/* x_out = block(x_in)  (open_clip ResidualAttentionBlock.forward) */
+int sc_block_fwd(const sc_block_desc* d, void* stream);
+/* dx_in (fp32 [rows,W]) = (d block / d x_in)^T dx_out; parameter grads into g_*.  dx_out_t / dx_in_t are optional copies
+ * of dx_out / dx_in in `dtype` (SC_BF16 only): pass the previous call's dx_in_t as the next call's dx_out_t to skip a cast. */
+int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser: torch.optim.AdamW defaults over one flat fp32 parameter buffer (sparsify_clip.py:730, :962/966).
+ * p *= 1 - lr*wd; m,v moments; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `step` is the 1-based step count.
+ * shadow_bf16 (may be NULL) receives a bf16 copy of the updated parameters.
+ * grad_scale multiplies g before use (1.0 normally).
+ * ---------------------------------------------------------------------------------------------- */
+int sc_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSIFY_HIP_H */

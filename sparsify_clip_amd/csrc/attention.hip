@@ -1,0 +1,202 @@
+// Small-sequence multi-head attention (S = 50 / 77, head dim 64) on packed qkv [B*S, 3W]
+// (nn.MultiheadAttention in_proj layout: q | k | v, head h = columns h*64 .. h*64+63 of each third).
+// One workgroup per (batch, head): the whole head (Q, K, V, and for the backward dO, P, dS) lives in LDS as fp32,
+// softmax statistics are wave reductions, nothing of size S x S ever reaches HBM.  fp32 arithmetic for both
+// storage dtypes, so the same kernel serves the fp32 parity path and the bf16 path.
+// The text tower uses the additive causal mask of open_clip (-inf above the diagonal).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;        // head dim
+constexpr int HDP = HD + 4;   // padded LDS row (floats): 272-B stride -> conflict-free ds_read_b128 across rows
+
+template <typename T>
+__device__ __forceinline__ void load_head(float* dst, const T* src, int64_t ld, int S, int tid) {
+    // dst[S][HDP] <- src[s*ld + 0..63]
+    for (int i = tid; i < S * (HD / 4); i += 256) {
+        const int s = i >> 4, c = (i & 15) * 4;
+        *(f32x4*)(dst + s * HDP + c) = io<T>::ld4(src + (int64_t)s * ld + c);
+    }
+}
+
+__device__ __forceinline__ float dot64(const float* a, const float* b) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+        const f32x4 x = *(const f32x4*)(a + c), y = *(const f32x4*)(b + c);
+        s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    return s;
+}
+
+// softmax row i of (scale * q_i . k_j) into p0 (j = lane) and p1 (j = 64 + lane); masked entries are 0
+template <bool CAUSAL>
+__device__ __forceinline__ void softmax_row(const float* Qs, const float* Ks, int S, int i, int lane, float scale, float& p0, float& p1) {
+    const int j0 = lane, j1 = 64 + lane;
+    const bool v0 = j0 < S && (!CAUSAL || j0 <= i), v1 = j1 < S && (!CAUSAL || j1 <= i);
+    const float s0 = v0 ? dot64(Qs + i * HDP, Ks + j0 * HDP) * scale : -INFINITY;
+    const float s1 = v1 ? dot64(Qs + i * HDP, Ks + j1 * HDP) * scale : -INFINITY;
+    const float m = wave_max(fmaxf(s0, s1));
+    p0 = v0 ? expf(s0 - m) : 0.f;
+    p1 = v1 ? expf(s1 - m) : 0.f;
+    const float inv = 1.0f / wave_sum(p0 + p1);
+    p0 *= inv;
+    p1 *= inv;
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const T* qkv, T* out, int S, int W, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Qs = lds;
+    float* Ks = Qs + S * HDP;
+    float* Vs = Ks + S * HDP;
+    float* Ps = Vs + S * HDP;   // [4][128]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t ld = 3 * (int64_t)W;
+    const T* base = qkv + (int64_t)b * S * ld + h * HD;
+    load_head<T>(Qs, base, ld, S, tid);
+    load_head<T>(Ks, base + W, ld, S, tid);
+    load_head<T>(Vs, base + 2 * W, ld, S, tid);
+    __syncthreads();
+    const int iters = (S + 3) / 4;
+    for (int it = 0; it < iters; ++it) {
+        const int i = it * 4 + w;
+        if (i < S) {
+            float p0, p1;
+            softmax_row<CAUSAL>(Qs, Ks, S, i, lane, scale, p0, p1);
+            Ps[w * 128 + lane] = p0;
+            Ps[w * 128 + 64 + lane] = p1;
+        }
+        __syncthreads();
+        if (i < S) {
+            const int jn = CAUSAL ? i + 1 : S;
+            float o = 0.f;
+            for (int j = 0; j < jn; ++j) o += Ps[w * 128 + j] * Vs[j * HDP + lane];
+            io<T>::st(out + ((int64_t)b * S + i) * W + h * HD + lane, o);
+        }
+    }
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* qkv, const T* d_out, T* d_qkv, int S, int W, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int SP = S + 1;
+    float* Qs = lds;
+    float* Ks = Qs + S * HDP;
+    float* Vs = Ks + S * HDP;
+    float* Os = Vs + S * HDP;     // dO
+    float* Pm = Os + S * HDP;     // [S][S+1] probabilities
+    float* Dm = Pm + S * SP;      // [S][S+1] dS (already scaled)
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t ld = 3 * (int64_t)W;
+    const T* base = qkv + (int64_t)b * S * ld + h * HD;
+    T* dbase = d_qkv + (int64_t)b * S * ld + h * HD;
+    load_head<T>(Qs, base, ld, S, tid);
+    load_head<T>(Ks, base + W, ld, S, tid);
+    load_head<T>(Vs, base + 2 * W, ld, S, tid);
+    load_head<T>(Os, d_out + (int64_t)b * S * W + h * HD, W, S, tid);
+    __syncthreads();
+    const int iters = (S + 3) / 4;
+    // phase A: per query row i: P, dS, dQ
+    for (int it = 0; it < iters; ++it) {
+        const int i = it * 4 + w;
+        if (i < S) {
+            float p0, p1;
+            softmax_row<CAUSAL>(Qs, Ks, S, i, lane, scale, p0, p1);
+            const int j0 = lane, j1 = 64 + lane;
+            const float dp0 = (j0 < S) ? dot64(Os + i * HDP, Vs + j0 * HDP) : 0.f;
+            const float dp1 = (j1 < S) ? dot64(Os + i * HDP, Vs + j1 * HDP) : 0.f;
+            const float delta = wave_sum(p0 * dp0 + p1 * dp1);
+            if (j0 < S) {
+                Pm[i * SP + j0] = p0;
+                Dm[i * SP + j0] = p0 * (dp0 - delta) * scale;
+            }
+            if (j1 < S) {
+                Pm[i * SP + j1] = p1;
+                Dm[i * SP + j1] = p1 * (dp1 - delta) * scale;
+            }
+        }
+        __syncthreads();
+        if (i < S) {
+            const int jn = CAUSAL ? i + 1 : S;
+            float dq = 0.f;
+            for (int j = 0; j < jn; ++j) dq += Dm[i * SP + j] * Ks[j * HDP + lane];
+            io<T>::st(dbase + (int64_t)i * ld + lane, dq);
+        }
+    }
+    __syncthreads();
+    // phase B: per key row j: dK, dV
+    for (int j = w; j < S; j += 4) {
+        const int i0 = CAUSAL ? j : 0;
+        float dk = 0.f, dv = 0.f;
+        for (int i = i0; i < S; ++i) {
+            dk += Dm[i * SP + j] * Qs[i * HDP + lane];
+            dv += Pm[i * SP + j] * Os[i * HDP + lane];
+        }
+        io<T>::st(dbase + (int64_t)j * ld + W + lane, dk);
+        io<T>::st(dbase + (int64_t)j * ld + 2 * W + lane, dv);
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return sc_set_error((int)e, "attention: cannot reserve %zu bytes of LDS: %s", bytes, hipGetErrorString(e));
+    }
+    return SC_OK;
+}
+
+int check(const char* who, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads) {
+    SC_REQUIRE(dtype == SC_BF16 || dtype == SC_F32, SC_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
+    SC_REQUIRE(batch > 0 && seq > 0 && heads > 0 && width == heads * HD, SC_ERR_SHAPE, "%s: width %lld must be heads*64", who, (long long)width);
+    SC_REQUIRE(seq <= 128, SC_ERR_SHAPE, "%s: sequence length %lld > 128 is not supported by the whole-head-in-LDS kernel", who, (long long)seq);
+    SC_REQUIRE(batch * heads < (1ll << 31), SC_ERR_SHAPE, "%s: grid too large", who);
+    return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                                void* stream) {
+    SC_TRY(check("sc_attention_fwd", dtype, batch, seq, width, heads));
+    SC_REQUIRE(qkv && out, SC_ERR_ARG, "sc_attention_fwd: null argument");
+    const size_t lds = ((size_t)3 * seq * HDP + 4 * 128) * sizeof(float);
+    const float scale = 0.125f;  // 1/sqrt(64)
+    const dim3 grid((unsigned)(batch * heads));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_FWD(T, C)                                                                                          \
+    do {                                                                                                          \
+        SC_TRY(set_lds(attention_fwd_kernel<T, C>, lds));                                                         \
+        hipLaunchKernelGGL((attention_fwd_kernel<T, C>), grid, dim3(256), lds, st, (const T*)qkv, (T*)out, (int)seq, (int)width, (int)heads, scale); \
+    } while (0)
+    if (dtype == SC_BF16) { if (causal) LAUNCH_FWD(bf16_t, true); else LAUNCH_FWD(bf16_t, false); }
+    else { if (causal) LAUNCH_FWD(float, true); else LAUNCH_FWD(float, false); }
+#undef LAUNCH_FWD
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
+                                int64_t heads, int causal, void* stream) {
+    SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
+    SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
+    const size_t lds = ((size_t)4 * seq * HDP + 2 * seq * (seq + 1)) * sizeof(float);
+    SC_REQUIRE(lds <= 160 * 1024, SC_ERR_SHAPE, "sc_attention_bwd: sequence length %lld needs %zu bytes of LDS (> 160 KiB)", (long long)seq, lds);
+    const float scale = 0.125f;
+    const dim3 grid((unsigned)(batch * heads));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BWD(T, C)                                                                                          \
+    do {                                                                                                          \
+        SC_TRY(set_lds(attention_bwd_kernel<T, C>, lds));                                                         \
+        hipLaunchKernelGGL((attention_bwd_kernel<T, C>), grid, dim3(256), lds, st, (const T*)qkv, (const T*)d_out, (T*)d_qkv, (int)seq, (int)width, (int)heads, scale); \
+    } while (0)
+    if (dtype == SC_BF16) { if (causal) LAUNCH_BWD(bf16_t, true); else LAUNCH_BWD(bf16_t, false); }
+    else { if (causal) LAUNCH_BWD(float, true); else LAUNCH_BWD(float, false); }
+#undef LAUNCH_BWD
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}

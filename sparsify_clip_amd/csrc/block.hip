@@ -1,0 +1,146 @@
+// One pre-LN residual attention block of the CLIP towers (open_clip ResidualAttentionBlock):
+//     x_mid = x_in  + out_proj(attention(in_proj(ln_1(x_in))))
+//     x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
+// forward and backward as a fixed sequence of launches on the caller's stream.  The residual stream and its
+// gradient stay fp32; GEMM operands are `dtype` (bf16 -> MFMA 16x16x32, fp32 -> MFMA 32x32x2).  Bias, exact-erf
+// GELU, GELU', and the residual adds are fused into the GEMM epilogues; LayerNorm backward also emits the
+// `dtype` copy of the residual gradient that the next GEMM consumes.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+int sc_gemm_f32_launch(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       float* c, int64_t ldc, const EpiParams& epi, hipStream_t stream);
+int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc,
+                           int out_dtype, const EpiParams& epi, hipStream_t stream);
+int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
+                           float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r);
+
+namespace {
+
+// y[rows,n] = x[rows,k] W[n,k]^T (+ epilogue); W in torch [out,in] layout
+int linear_fwd(int dtype, int64_t rows, int64_t n, int64_t k, const void* x, const void* w, void* y, int out_dtype, const EpiParams& epi,
+               hipStream_t st) {
+    if (dtype == SC_BF16) return sc_gemm_bf16_nt_launch(rows, n, k, x, k, w, k, y, n, out_dtype, epi, st);
+    return sc_gemm_f32_launch(0, 1, rows, n, k, (const float*)x, k, (const float*)w, k, (float*)y, n, epi, st);
+}
+// dx[rows,k] = dy[rows,n] W[n,k]  (bf16: NT against the [in,out] copy wt[k,n])
+int linear_dx(int dtype, int64_t rows, int64_t n, int64_t k, const void* dy, const void* w, const void* wt, void* dx, const EpiParams& epi,
+              hipStream_t st) {
+    if (dtype == SC_BF16) return sc_gemm_bf16_nt_launch(rows, k, n, dy, n, wt, n, dx, k, SC_BF16, epi, st);
+    return sc_gemm_f32_launch(0, 0, rows, k, n, (const float*)dy, n, (const float*)w, k, (float*)dx, k, epi, st);
+}
+// dw[n,k] (+)= dy[rows,n]^T x[rows,k]
+int linear_dw(int dtype, int64_t rows, int64_t n, int64_t k, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes,
+              hipStream_t st) {
+    if (dtype == SC_BF16) return sc_gemm_bf16_tn_launch(n, k, rows, dy, n, x, k, dw, k, 1.f, accumulate ? 1.f : 0.f, ws, ws_bytes, st);
+    return sc_gemm_f32_launch(1, 0, n, k, rows, (const float*)dy, n, (const float*)x, k, dw, k, epi_plain(1.f, accumulate ? 1.f : 0.f), st);
+}
+
+int check_desc(const sc_block_desc* d, const char* who) {
+    SC_REQUIRE(d != nullptr, SC_ERR_ARG, "%s: null descriptor", who);
+    SC_REQUIRE(d->dtype == SC_BF16 || d->dtype == SC_F32, SC_ERR_DTYPE, "%s: bad dtype %d", who, d->dtype);
+    SC_REQUIRE(d->batch > 0 && d->seq > 0 && d->width > 0 && d->heads > 0 && d->mlp_width > 0, SC_ERR_SHAPE, "%s: bad dims", who);
+    SC_REQUIRE(d->width == d->heads * 64, SC_ERR_SHAPE, "%s: width must be heads*64", who);
+    SC_REQUIRE(d->width % 64 == 0 && d->mlp_width % 64 == 0, SC_ERR_SHAPE, "%s: widths must be multiples of 64", who);
+    SC_REQUIRE(d->x_in && d->x_mid && d->x_out && d->ln1_out && d->qkv && d->attn_out && d->ln2_out && d->h_pre && d->h_act && d->ln1_mean &&
+                   d->ln1_rstd && d->ln2_mean && d->ln2_rstd,
+               SC_ERR_ARG, "%s: null activation buffer", who);
+    SC_REQUIRE(d->w_qkv && d->w_o && d->w_fc1 && d->w_fc2 && d->ln1_g && d->ln1_b && d->ln2_g && d->ln2_b && d->b_qkv && d->b_o && d->b_fc1 && d->b_fc2,
+               SC_ERR_ARG, "%s: null parameter", who);
+    return SC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype) {
+    if (rows <= 0 || width <= 0 || mlp_width <= 0) return 0;
+    size_t need = (size_t)256 * 2 * (size_t)width * sizeof(float);                       // LayerNorm partials
+    const size_t widest = (size_t)(mlp_width > 3 * width ? mlp_width : 3 * width);
+    need = need > 256 * widest * sizeof(float) ? need : 256 * widest * sizeof(float);   // column-sum partials
+    if (dtype == SC_BF16) {
+        const int64_t shapes[4][2] = {{3 * width, width}, {width, width}, {mlp_width, width}, {width, mlp_width}};
+        for (auto& s : shapes) {
+            const size_t w = sc_gemm_bf16_tn_ws(s[0], s[1], rows);
+            need = need > w ? need : w;
+        }
+    }
+    return ((need + 255) / 256) * 256;
+}
+
+extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
+    SC_TRY(check_desc(d, "sc_block_fwd"));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = d->batch * d->seq, W = d->width, MLP = d->mlp_width;
+    const int dt = d->dtype;
+    // ln_1 -> in_proj (+bias)
+    SC_TRY(sc_layernorm_fwd(d->x_in, rows, W, d->ln1_g, d->ln1_b, d->ln1_out, dt, d->ln1_mean, d->ln1_rstd, stream));
+    EpiParams e = epi_plain();
+    e.bias = d->b_qkv;
+    SC_TRY(linear_fwd(dt, rows, 3 * W, W, d->ln1_out, d->w_qkv, d->qkv, dt, e, st));
+    SC_TRY(sc_attention_fwd(d->qkv, d->attn_out, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
+    // out_proj (+bias) + residual -> fp32 x_mid
+    e = epi_plain();
+    e.bias = d->b_o; e.resid = d->x_in; e.resid_dtype = SC_F32; e.ld_aux = W;
+    SC_TRY(linear_fwd(dt, rows, W, W, d->attn_out, d->w_o, d->x_mid, SC_F32, e, st));
+    // ln_2 -> c_fc (+bias, keep pre-activation) -> GELU
+    SC_TRY(sc_layernorm_fwd(d->x_mid, rows, W, d->ln2_g, d->ln2_b, d->ln2_out, dt, d->ln2_mean, d->ln2_rstd, stream));
+    e = epi_plain();
+    e.bias = d->b_fc1; e.pre_out = d->h_pre; e.act = 1; e.ld_aux = MLP;
+    SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_act, dt, e, st));
+    // c_proj (+bias) + residual -> fp32 x_out
+    e = epi_plain();
+    e.bias = d->b_fc2; e.resid = d->x_mid; e.resid_dtype = SC_F32; e.ld_aux = W;
+    SC_TRY(linear_fwd(dt, rows, W, MLP, d->h_act, d->w_fc2, d->x_out, SC_F32, e, st));
+    return SC_OK;
+}
+
+extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream) {
+    SC_TRY(check_desc(d, "sc_block_bwd"));
+    SC_REQUIRE(dx_out && dx_in, SC_ERR_ARG, "sc_block_bwd: null gradient buffer");
+    SC_REQUIRE(d->d_h && d->d_ln && d->d_qkv && d->d_attn && d->dx_mid && d->ws, SC_ERR_ARG, "sc_block_bwd: null scratch buffer");
+    SC_REQUIRE(d->g_ln1_g && d->g_ln1_b && d->g_w_qkv && d->g_b_qkv && d->g_w_o && d->g_b_o && d->g_ln2_g && d->g_ln2_b && d->g_w_fc1 && d->g_b_fc1 &&
+                   d->g_w_fc2 && d->g_b_fc2,
+               SC_ERR_ARG, "sc_block_bwd: null gradient output");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = d->batch * d->seq, W = d->width, MLP = d->mlp_width;
+    const int dt = d->dtype, acc = d->accumulate;
+    const bool bf = dt == SC_BF16;
+    if (bf) SC_REQUIRE(d->wt_qkv && d->wt_o && d->wt_fc1 && d->wt_fc2 && d->d_res_t, SC_ERR_ARG, "sc_block_bwd: bf16 needs the [in,out] weight copies and d_res_t");
+    SC_REQUIRE(d->ws_bytes >= sc_block_workspace_bytes(rows, W, MLP, dt), SC_ERR_WORKSPACE, "sc_block_bwd: workspace too small");
+
+    // GEMM-operand view of dx_out
+    const void* g = dx_out;
+    if (bf) {
+        if (dx_out_t) g = dx_out_t;
+        else {
+            SC_TRY(sc_cast_f32_to_bf16(dx_out, d->d_res_t, rows * W, stream));
+            g = d->d_res_t;
+        }
+    }
+    // ---- MLP half: c_proj, GELU', c_fc
+    SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, d->ws, d->ws_bytes, st));
+    SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));
+    EpiParams e = epi_plain();
+    e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
+    SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
+    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, d->ws, d->ws_bytes, st));
+    SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, d->ws, d->ws_bytes, stream));
+    SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
+    // dx_mid = dx_out + LN2'(d_ln)
+    SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_mid, d->ln2_mean, d->ln2_rstd, d->ln2_g, rows, W, dx_out, d->dx_mid, bf ? d->d_res_t : nullptr,
+                            d->g_ln2_g, d->g_ln2_b, acc, d->ws, d->ws_bytes, stream));
+    const void* gm = bf ? (const void*)d->d_res_t : (const void*)d->dx_mid;
+    // ---- attention half: out_proj, attention, in_proj
+    SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, d->ws, d->ws_bytes, st));
+    SC_TRY(sc_colsum(d->dx_mid, SC_F32, rows, W, W, d->g_b_o, acc, d->ws, d->ws_bytes, stream));
+    SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
+    SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
+    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, d->ws, d->ws_bytes, st));
+    SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
+    SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
+    // dx_in = dx_mid + LN1'(d_ln)
+    SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,
+                            d->g_ln1_b, acc, d->ws, d->ws_bytes, stream));
+    return SC_OK;
+}

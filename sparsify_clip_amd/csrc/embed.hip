@@ -1,0 +1,276 @@
+// Stem / head data movement of the two towers: im2col for the patch-embedding GEMM, cls/positional token assembly,
+// token-embedding gather and its deterministic scatter-add, pooled-row gather/scatter, dtype casts and the
+// [in,out] bf16 weight copies.  All HBM-bound, coalesced along the contiguous dimension.
+#include "common.h"
+
+namespace {
+
+// patches[(b,py,px)][(c,ky,kx)] = img[b][c][py*P+ky][px*P+kx]; columns >= 3*P*P are zero padding
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* img, int res, int patch, int g, int kreal, int kpad, T* out) {
+    const int64_t row = blockIdx.x;   // b*g*g + py*g + px
+    const int b = (int)(row / (g * g)), pp = (int)(row % (g * g)), py = pp / g, px = pp % g;
+    const float* src = img + (int64_t)b * 3 * res * res;
+    for (int col = threadIdx.x; col < kpad; col += 256) {
+        float v = 0.f;
+        if (col < kreal) {
+            const int c = col / (patch * patch), rem = col % (patch * patch), ky = rem / patch, kx = rem % patch;
+            v = src[((int64_t)c * res + py * patch + ky) * res + px * patch + kx];
+        }
+        io<T>::st(out + row * kpad + col, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_tokens_fwd_kernel(const T* patch_out, const float* cls, const float* pos, int seq, int width, float* x) {
+    const int64_t row = blockIdx.x;   // b*seq + s
+    const int b = (int)(row / seq), s = (int)(row % seq);
+    for (int c = threadIdx.x * 4; c < width; c += 1024) {
+        f32x4 v = *(const f32x4*)(pos + (int64_t)s * width + c);
+        if (s == 0) v += *(const f32x4*)(cls + c);
+        else v += io<T>::ld4(patch_out + ((int64_t)b * (seq - 1) + (s - 1)) * width + c);
+        *(f32x4*)(x + row * width + c) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_tokens_bwd_copy_kernel(const float* dx, int seq, int width, T* d_patch_out) {
+    const int64_t prow = blockIdx.x;  // b*(seq-1) + p
+    const int b = (int)(prow / (seq - 1)), p = (int)(prow % (seq - 1));
+    for (int c = threadIdx.x * 4; c < width; c += 1024)
+        io<T>::st4(d_patch_out + prow * width + c, *(const f32x4*)(dx + ((int64_t)b * seq + 1 + p) * width + c));
+}
+
+// out[s][c] (+)= sum_b dx[b][s][c];  optionally extra[c] (+)= the s == 0 row (class-embedding gradient)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* dx, int batch, int seq, int width, float* out, float* extra, int accumulate) {
+    const int s = blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= width) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < batch; ++b) acc += *(const f32x4*)(dx + ((int64_t)b * seq + s) * width + c);
+    if (out) {
+        f32x4* o = (f32x4*)(out + (int64_t)s * width + c);
+        *o = accumulate ? *o + acc : acc;
+    }
+    if (extra && s == 0) {
+        f32x4* o = (f32x4*)(extra + c);
+        *o = accumulate ? *o + acc : acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* tokens, const float* tok_emb, const float* pos, int seq, int width,
+                                                             int64_t vocab, float* x) {
+    const int64_t row = blockIdx.x;
+    const int s = (int)(row % seq);
+    int64_t tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    for (int c = threadIdx.x * 4; c < width; c += 1024)
+        *(f32x4*)(x + row * width + c) = *(const f32x4*)(tok_emb + tok * width + c) + *(const f32x4*)(pos + (int64_t)s * width + c);
+}
+
+// one wave per sorted position; only the head of a run of equal tokens works: it adds the run's rows in sorted order
+__global__ __launch_bounds__(256) void token_scatter_kernel(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted,
+                                                            int width, int64_t vocab, float* d_tok_emb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_sorted) return;
+    const int64_t tok = sorted_tokens[i];
+    if (i > 0 && sorted_tokens[i - 1] == tok) return;
+    if (tok < 0 || tok >= vocab) return;
+    for (int c0 = 0; c0 < width; c0 += 256) {
+        const int c = c0 + lane * 4;
+        if (c >= width) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = i; k < n_sorted && sorted_tokens[k] == tok; ++k) acc += *(const f32x4*)(dx + order[k] * width + c);
+        f32x4* o = (f32x4*)(d_tok_emb + tok * width + c);
+        *o += acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_tokens_kernel(const int64_t* tokens, int64_t batch, int seq, int32_t* eot) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= batch) return;
+    int64_t best = tokens[b * seq];
+    int idx = 0;
+    for (int s = 1; s < seq; ++s) {
+        const int64_t v = tokens[b * seq + s];
+        if (v > best) { best = v; idx = s; }
+    }
+    eot[b] = idx;
+}
+
+// GATHER: out[b] = x[b*seq + idx[b]] ; else x[b*seq + idx[b]] = d_out[b] (dx pre-zeroed)
+template <bool GATHER>
+__global__ __launch_bounds__(256) void pool_kernel(const float* src, const int32_t* idx, int seq, int width, float* dst) {
+    const int64_t b = blockIdx.x;
+    const int64_t row = b * seq + (idx ? idx[b] : 0);
+    for (int c = threadIdx.x * 4; c < width; c += 1024) {
+        if (GATHER) *(f32x4*)(dst + b * width + c) = *(const f32x4*)(src + row * width + c);
+        else *(f32x4*)(dst + row * width + c) = *(const f32x4*)(src + b * width + c);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) io<bf16_t>::st4(dst + i, *(const f32x4*)(src + i));
+    else
+        for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+}
+
+// dst[c][r] = bf16(src[r][c]) through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, int64_t rows, int64_t cols, bf16_t* dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < cols && r < rows) dst[c * rows + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* shadow, int64_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i) * gscale, mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pv[j] *= 1.0f - lr * wd;
+            mv[j] = b1 * mv[j] + (1.0f - b1) * gv[j];
+            vv[j] = b2 * vv[j] + (1.0f - b2) * gv[j] * gv[j];
+            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+            pv[j] -= (lr / bc1) * (mv[j] / denom);
+        }
+        *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+        if (shadow) io<bf16_t>::st4(shadow + i, pv);
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            float pv = p[j] * (1.0f - lr * wd);
+            const float gv = g[j] * gscale;
+            const float mv = b1 * m[j] + (1.0f - b1) * gv, vv = b2 * v[j] + (1.0f - b2) * gv * gv;
+            pv -= (lr / bc1) * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+            p[j] = pv; m[j] = mv; v[j] = vv;
+            if (shadow) shadow[j] = f32_to_bf16(pv);
+        }
+    }
+}
+
+}  // namespace
+
+#define ST(x) ((hipStream_t)(x))
+
+extern "C" int sc_im2col(const float* images, int64_t batch, int64_t res, int64_t patch, int64_t kpad, void* out, int dtype, void* stream) {
+    SC_REQUIRE(images && out && batch > 0 && patch > 0 && res % patch == 0, SC_ERR_SHAPE, "sc_im2col: bad shape");
+    const int g = (int)(res / patch), kreal = (int)(3 * patch * patch);
+    SC_REQUIRE(kpad >= kreal, SC_ERR_SHAPE, "sc_im2col: kpad %lld < 3*P*P", (long long)kpad);
+    const dim3 grid((unsigned)(batch * g * g));
+    if (dtype == SC_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), images, (int)res, (int)patch, g, kreal, (int)kpad, (bf16_t*)out);
+    else if (dtype == SC_F32) hipLaunchKernelGGL(im2col_kernel<float>, grid, dim3(256), 0, ST(stream), images, (int)res, (int)patch, g, kreal, (int)kpad, (float*)out);
+    else return sc_set_error(SC_ERR_DTYPE, "sc_im2col: bad dtype");
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_vit_tokens_fwd(const void* patch_out, int dtype, const float* cls, const float* pos, int64_t batch, int64_t seq, int64_t width,
+                                 float* x, void* stream) {
+    SC_REQUIRE(patch_out && cls && pos && x && batch > 0 && seq > 1 && width % 4 == 0, SC_ERR_ARG, "sc_vit_tokens_fwd: bad argument");
+    const dim3 grid((unsigned)(batch * seq));
+    if (dtype == SC_BF16) hipLaunchKernelGGL(vit_tokens_fwd_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)patch_out, cls, pos, (int)seq, (int)width, x);
+    else if (dtype == SC_F32) hipLaunchKernelGGL(vit_tokens_fwd_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)patch_out, cls, pos, (int)seq, (int)width, x);
+    else return sc_set_error(SC_ERR_DTYPE, "sc_vit_tokens_fwd: bad dtype");
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_vit_tokens_bwd(const float* dx, int64_t batch, int64_t seq, int64_t width, void* d_patch_out, int dtype, float* d_cls, float* d_pos,
+                                 int accumulate, void* stream) {
+    SC_REQUIRE(dx && d_patch_out && d_cls && d_pos && batch > 0 && seq > 1 && width % 4 == 0, SC_ERR_ARG, "sc_vit_tokens_bwd: bad argument");
+    const dim3 grid((unsigned)(batch * (seq - 1)));
+    if (dtype == SC_BF16) hipLaunchKernelGGL(vit_tokens_bwd_copy_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), dx, (int)seq, (int)width, (bf16_t*)d_patch_out);
+    else if (dtype == SC_F32) hipLaunchKernelGGL(vit_tokens_bwd_copy_kernel<float>, grid, dim3(256), 0, ST(stream), dx, (int)seq, (int)width, (float*)d_patch_out);
+    else return sc_set_error(SC_ERR_DTYPE, "sc_vit_tokens_bwd: bad dtype");
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 1024), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
+                       d_pos, d_cls, accumulate);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_text_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos, int64_t batch, int64_t seq, int64_t width,
+                                 int64_t vocab, float* x, void* stream) {
+    SC_REQUIRE(tokens && tok_emb && pos && x && batch > 0 && seq > 0 && width % 4 == 0 && vocab > 0, SC_ERR_ARG, "sc_text_embed_fwd: bad argument");
+    hipLaunchKernelGGL(text_embed_fwd_kernel, dim3((unsigned)(batch * seq)), dim3(256), 0, ST(stream), tokens, tok_emb, pos, (int)seq, (int)width, vocab, x);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_text_embed_bwd(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted, int64_t batch, int64_t seq,
+                                 int64_t width, int64_t vocab, float* d_tok_emb, float* d_pos, int accumulate, void* stream) {
+    SC_REQUIRE(dx && sorted_tokens && order && d_tok_emb && d_pos && batch > 0 && seq > 0 && width % 4 == 0, SC_ERR_ARG, "sc_text_embed_bwd: bad argument");
+    SC_REQUIRE(n_sorted >= 0 && n_sorted <= batch * seq, SC_ERR_SHAPE, "sc_text_embed_bwd: n_sorted out of range");
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(d_tok_emb, 0, (size_t)vocab * width * sizeof(float), ST(stream));
+        if (e != hipSuccess) return sc_set_error((int)e, "sc_text_embed_bwd: memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 1024), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
+                       d_pos, (float*)nullptr, accumulate);
+    if (n_sorted > 0)
+        hipLaunchKernelGGL(token_scatter_kernel, dim3((unsigned)sc_cdiv(n_sorted, 4)), dim3(256), 0, ST(stream), dx, sorted_tokens, order, n_sorted, (int)width,
+                           vocab, d_tok_emb);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_argmax_tokens(const int64_t* tokens, int64_t batch, int64_t seq, int32_t* eot, void* stream) {
+    SC_REQUIRE(tokens && eot && batch > 0 && seq > 0, SC_ERR_ARG, "sc_argmax_tokens: bad argument");
+    hipLaunchKernelGGL(argmax_tokens_kernel, dim3((unsigned)sc_cdiv(batch, 256)), dim3(256), 0, ST(stream), tokens, batch, (int)seq, eot);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_pool_gather(const float* x, const int32_t* idx, int64_t batch, int64_t seq, int64_t width, float* out, void* stream) {
+    SC_REQUIRE(x && out && batch > 0 && seq > 0 && width % 4 == 0, SC_ERR_ARG, "sc_pool_gather: bad argument");
+    hipLaunchKernelGGL(pool_kernel<true>, dim3((unsigned)batch), dim3(256), 0, ST(stream), x, idx, (int)seq, (int)width, out);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+extern "C" int sc_pool_scatter(const float* d_out, const int32_t* idx, int64_t batch, int64_t seq, int64_t width, float* dx, void* stream) {
+    SC_REQUIRE(d_out && dx && batch > 0 && seq > 0 && width % 4 == 0, SC_ERR_ARG, "sc_pool_scatter: bad argument");
+    hipLaunchKernelGGL(pool_kernel<false>, dim3((unsigned)batch), dim3(256), 0, ST(stream), d_out, idx, (int)seq, (int)width, dx);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    SC_REQUIRE(src && dst && n >= 0, SC_ERR_ARG, "sc_cast_f32_to_bf16: bad argument");
+    if (n == 0) return SC_OK;
+    SC_REQUIRE(sc_aligned(src, 16) && sc_aligned(dst, 8), SC_ERR_ALIGN, "sc_cast_f32_to_bf16: misaligned");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)sc_cdiv(sc_cdiv(n, 4), 256)), dim3(256), 0, ST(stream), src, (bf16_t*)dst, n);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+extern "C" int sc_transpose_cast_bf16(const float* src, int64_t rows, int64_t cols, void* dst, void* stream) {
+    SC_REQUIRE(src && dst && rows > 0 && cols > 0, SC_ERR_ARG, "sc_transpose_cast_bf16: bad argument");
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3((unsigned)sc_cdiv(cols, 32), (unsigned)sc_cdiv(rows, 32)), dim3(256), 0, ST(stream), src, rows, cols, (bf16_t*)dst);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, float grad_scale, void* stream) {
+    SC_REQUIRE(p && g && m && v && n > 0 && step >= 1, SC_ERR_ARG, "sc_adamw_step: bad argument");
+    SC_REQUIRE(sc_aligned(p, 16) && sc_aligned(g, 16) && sc_aligned(m, 16) && sc_aligned(v, 16) && sc_aligned(shadow_bf16, 8), SC_ERR_ALIGN, "sc_adamw_step: misaligned");
+    const float bc1 = 1.0f - (float)pow((double)beta1, (double)step);
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)sc_cdiv(sc_cdiv(n, 4), 256)), dim3(256), 0, ST(stream), p, g, m, v, (bf16_t*)shadow_bf16, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}

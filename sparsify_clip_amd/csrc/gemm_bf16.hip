@@ -1,0 +1,358 @@
+// bf16 MFMA GEMMs for the encoder towers (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+//  NT  C[M,N] = A[M,K] B[N,K]^T   both operands K-contiguous: forward linears (x W^T) and, with the [in,out]
+//      weight copies, the activation gradients (dX = dY W).
+//  TN  C[M,N] = sum_r A[r][m] B[r][n]   both operands contraction-strided: weight gradients dW = dY^T X.
+//      The strided operands are staged row-major (coalesced) and read back transposed with
+//      ds_read_b64_tr_b16, so no transposed activation copy ever goes through HBM.
+//
+// Common structure: 128x128 output tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile =
+// 4x4 MFMA tiles; K-step 64; two LDS buffers of (16 KiB A + 16 KiB B) filled by global_load_lds_dwordx4
+// (LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and undone
+// on the read - cdna_hip_programming.md rule 21).  The MFMA is issued with the operands swapped
+// (D = B_tile A_tile^T) so that each lane's 4 accumulator registers are 4 CONSECUTIVE columns n of one row m:
+// the epilogue then loads/stores 8-byte (bf16) or 16-byte (fp32) pieces instead of 2-byte scalars.
+// Workgroup ids are remapped so that each XCD walks a contiguous range of tiles (A-panel reuse in its own L2).
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int TILE = 128, KSTEP = 64;
+constexpr int OPER_BYTES = 16384, BUF_BYTES = 32768;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) bf16x4* ltr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+struct GemmBf16Params {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    int M, N, K;          // TN: K is the contraction length R
+    int64_t lda, ldb, ldc;
+    int tiles_m, tiles_n;
+    int splits, k_per_split;   // TN only (k_per_split in units of KSTEP tiles)
+    float* partial;            // TN split-R partial slabs [splits][M][N] or null
+    EpiParams epi;
+};
+
+// bijective XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous chunk of tiles
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------ NT
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (tile / p.tiles_n) * TILE, n0 = (tile % p.tiles_n) * TILE;
+
+    // staging: one wave instruction = 8 rows x 128 B; lane -> (row l>>3, slot l&7) holds logical chunk slot^(row&7)
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 32 + q * 8 + srow;
+        ga[q] = p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + schunk * 8;
+        gb[q] = p.B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + schunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* abase = smem + buf * BUF_BYTES + (wave * 32) * 128;
+        char* bbase = abase + OPER_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(ga[q] + kt * KSTEP, abase + q * 8 * 128);
+            glds16(gb[q] + kt * KSTEP, bbase + q * 8 * 128);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / KSTEP;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* abase = smem + cur * BUF_BYTES + (wm * 64 + frow) * 128;
+        const char* bbase = smem + cur * BUF_BYTES + OPER_BYTES + (wn * 64 + frow) * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int pos = ((4 * s + fq) ^ (lane & 7)) * 16;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(abase + i * 16 * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(bbase + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // D[n][m]: lane holds m = ..+(lane&15), n = ..+4*(lane>>4)+reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+            if (n >= p.N) continue;
+            if (OUT_F32) {
+                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                *(f32x4*)cp = epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, cp);
+            } else {
+                bf16_t* cp = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
+                io<bf16_t>::st4(cp, epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, nullptr));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ TN
+// LDS tile: [64 r][128 cols] bf16, 256-B rows.  32-B slot swizzle so that the 8 rows a 32-lane half touches in one
+// ds_read_b64_tr_b16 fall on 8 different 32-B slots of the 256-B bank row.
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, ntiles * p.splits);
+    const int split = id / ntiles, tile = id % ntiles;
+    const int m0 = (tile / p.tiles_n) * TILE, n0 = (tile % p.tiles_n) * TILE;
+    const int kt_begin = split * p.k_per_split;
+    const int nk_total = (p.K + KSTEP - 1) / KSTEP;
+    const int kt_end = min(nk_total, kt_begin + p.k_per_split);
+
+    // staging: one wave instruction = 4 rows x 256 B; lane -> (row l>>4, slot l&15)
+    const int srow = lane >> 4;
+    int acol[4], bcol[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 16 + q * 4 + srow;
+        const int c = (lane & 15) ^ tn_swz(r);
+        acol[q] = min(m0 + c * 8, p.M - 8);
+        bcol[q] = min(n0 + c * 8, p.N - 8);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* abase = smem + buf * BUF_BYTES + (wave * 16) * 256;
+        char* bbase = abase + OPER_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t gr = min(kt * KSTEP + wave * 16 + q * 4 + srow, p.K - 1);
+            glds16(p.A + gr * p.lda + acol[q], abase + q * 4 * 256);
+            glds16(p.B + gr * p.ldb + bcol[q], bbase + q * 4 * 256);
+        }
+    };
+    // rows past the contraction length must contribute zero (the clamped loads above fetched a valid row)
+    auto zero_tail = [&](int buf, int kt) {
+        const int valid = p.K - kt * KSTEP;
+        if (valid >= KSTEP) return;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int piece = q * 256 + t;          // 2048 pieces of 16 B over both operand tiles
+            const int row = (piece & 1023) >> 4;
+            if (row >= valid) *(uint4*)(smem + buf * BUF_BYTES + piece * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt_begin < kt_end) {
+        stage(0, kt_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        zero_tail(0, kt_begin);
+    }
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    const int swz = (q4 | ((g & 1) << 2)) << 1;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
+        const char* abase = smem + cur * BUF_BYTES;
+        const char* bbase = abase + OPER_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 32 * s + 8 * g + 4 * h + q4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ca = ((wm * 64 + 16 * i) >> 3) + (pp >> 1);
+                    const int cb = ((wn * 64 + 16 * i) >> 3) + (pp >> 1);
+                    const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(abase + row * 256 + ((ca ^ swz) << 4) + ((pp & 1) << 3)));
+                    const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(bbase + row * 256 + ((cb ^ swz) << 4) + ((pp & 1) << 3)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        af[i][4 * h + e] = va[e];
+                        bfr[i][4 * h + e] = vb[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < kt_end) zero_tail(cur ^ 1, kt + 1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + i16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * g;
+            if (n >= p.N) continue;
+            if (p.partial) {
+                *(f32x4*)(p.partial + ((int64_t)split * p.M + m) * p.N + n) = acc[i][j];
+            } else {
+                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                f32x4 v = acc[i][j] * p.epi.alpha;
+                if (p.epi.beta != 0.f) v += *(const f32x4*)cp * p.epi.beta;
+                *(f32x4*)cp = v;
+            }
+        }
+    }
+}
+
+// C = alpha * sum_s partial[s] + beta * C   (fixed order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, int64_t mn, int n, float* c, int64_t ldc,
+                                                            float alpha, float beta) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= mn) return;
+    f32x4 s = *(const f32x4*)(partial + i4);
+    for (int k = 1; k < splits; ++k) s += *(const f32x4*)(partial + (int64_t)k * mn + i4);
+    float* cp = c + (i4 / n) * ldc + (i4 % n);
+    f32x4 v = s * alpha;
+    if (beta != 0.f) v += *(const f32x4*)cp * beta;
+    *(f32x4*)cp = v;
+}
+
+int tn_splits(int64_t m, int64_t n, int64_t r) {
+    const int64_t tiles = sc_cdiv(m, TILE) * sc_cdiv(n, TILE);
+    const int64_t nk = sc_cdiv(r, KSTEP);
+    int64_t s = sc_cdiv(768, tiles);
+    const int64_t cap = nk / 4 > 1 ? nk / 4 : 1;
+    if (s > cap) s = cap;
+    if (s > 32) s = 32;
+    return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c,
+                           int64_t ldc, int out_dtype, const EpiParams& epi, hipStream_t stream) {
+    SC_REQUIRE(m > 0 && n > 0 && k > 0, SC_ERR_SHAPE, "sc_gemm_bf16_nt: empty problem");
+    SC_REQUIRE(a && b && c, SC_ERR_ARG, "sc_gemm_bf16_nt: null operand");
+    SC_REQUIRE(k % KSTEP == 0, SC_ERR_SHAPE, "sc_gemm_bf16_nt: K = %lld must be a multiple of 64", (long long)k);
+    SC_REQUIRE(n % 4 == 0, SC_ERR_SHAPE, "sc_gemm_bf16_nt: N = %lld must be a multiple of 4", (long long)n);
+    SC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= k && ldb >= k && ldc >= n, SC_ERR_SHAPE, "sc_gemm_bf16_nt: bad leading dimension");
+    SC_REQUIRE(sc_aligned(a, 16) && sc_aligned(b, 16) && sc_aligned(c, 16), SC_ERR_ALIGN, "sc_gemm_bf16_nt: operands must be 16-byte aligned");
+    SC_REQUIRE(out_dtype == SC_BF16 || out_dtype == SC_F32, SC_ERR_DTYPE, "sc_gemm_bf16_nt: bad out dtype");
+    SC_REQUIRE(!(epi.pre_out || epi.resid || epi.dgelu_pre) || epi.ld_aux % 4 == 0, SC_ERR_SHAPE, "sc_gemm_bf16_nt: ld_aux must be a multiple of 4");
+    SC_REQUIRE(epi.beta == 0.f || out_dtype == SC_F32, SC_ERR_ARG, "sc_gemm_bf16_nt: beta needs an fp32 C");
+    GemmBf16Params p;
+    p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
+    p.M = (int)m; p.N = (int)n; p.K = (int)k;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
+    p.splits = 1; p.k_per_split = 0; p.partial = nullptr;
+    p.epi = epi;
+    const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+    if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r) {
+    const int s = tn_splits(m, n, r);
+    return s > 1 ? (size_t)s * m * n * sizeof(float) : 0;
+}
+
+int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c,
+                           int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream) {
+    SC_REQUIRE(m > 0 && n > 0 && r > 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn: empty problem");
+    SC_REQUIRE(a && b && c, SC_ERR_ARG, "sc_gemm_bf16_tn: null operand");
+    SC_REQUIRE(m % 8 == 0 && n % 8 == 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn: M and N must be multiples of 8");
+    SC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= m && ldb >= n && ldc >= n, SC_ERR_SHAPE, "sc_gemm_bf16_tn: bad leading dimension");
+    SC_REQUIRE(sc_aligned(a, 16) && sc_aligned(b, 16) && sc_aligned(c, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: operands must be 16-byte aligned");
+    GemmBf16Params p;
+    p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
+    p.M = (int)m; p.N = (int)n; p.K = (int)r;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
+    p.splits = tn_splits(m, n, r);
+    const int64_t nk = sc_cdiv(r, KSTEP);
+    p.k_per_split = (int)sc_cdiv(nk, p.splits);
+    p.splits = (int)sc_cdiv(nk, p.k_per_split);
+    p.partial = nullptr;
+    p.epi = epi_plain(alpha, beta);
+    if (p.splits > 1) {
+        SC_REQUIRE(ws && ws_bytes >= (size_t)p.splits * m * n * sizeof(float), SC_ERR_WORKSPACE, "sc_gemm_bf16_tn: workspace too small");
+        SC_REQUIRE(sc_aligned(ws, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: workspace must be 16-byte aligned");
+        p.partial = (float*)ws;
+    }
+    const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n * p.splits);
+    hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+    SC_CHECK_LAUNCH();
+    if (p.splits > 1) {
+        const int64_t mn = m * n;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)sc_cdiv(mn / 4, 256)), dim3(256), 0, stream, p.partial, p.splits, mn, (int)n, c, ldc,
+                           alpha, beta);
+        SC_CHECK_LAUNCH();
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_gemm_bf16_nt(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc,
+                               int out_dtype, const sc_gemm_epilogue* e, void* stream) {
+    EpiParams epi;
+    SC_TRY(epi_from_abi(e, SC_BF16, epi));
+    return sc_gemm_bf16_nt_launch(m, n, k, a, lda, b, ldb, c, ldc, out_dtype, epi, (hipStream_t)stream);
+}
+extern "C" size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t r) {
+    if (m <= 0 || n <= 0 || r <= 0) return 0;
+    return sc_gemm_bf16_tn_ws(m, n, r);
+}
+extern "C" int sc_gemm_bf16_tn(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
+                               float alpha, float beta, void* ws, size_t ws_bytes, void* stream) {
+    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream);
+}
