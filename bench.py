@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Headline benchmark: image-text pairs/sec of the full CLIP training step (both encoders fwd+bwd, global-batch loss
+head, AdamW, DP collectives) on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload (BASELINE.json): experiment_6 loss stack (anchor + lalign + lunif(centroids), main phase) on ViT-B/32 in bf16,
+synthetic 3x224x224 images + 77-token captions, LOCAL batch 1024 per GPU - weak scaling, so that N = 8 is the metric's
+global batch 8192.  Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the dominant kernel
+(the bf16 NT MFMA GEMM) by replaying one step's GEMM launches; `cpu_baseline` times the oracle's CPU step (fp32, plain torch)
+on a bounded sample on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as tdist  # noqa: E402
+
+GF_PER_PAIR = {"ViT-B-32": 44.33, "ViT-L-14": 525.98}     # fwd+bwd = 3x fwd GFLOP per (image, caption) pair, SURVEY 8d
+PEAK_BF16_TFLOPS = 2500.0                                   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--local-batch", type=int, default=1024)
+    p.add_argument("--model", type=str, default="ViT-B-32")
+    p.add_argument("--experiment", type=str, default="experiment_6", help="which reference YAML (by prefix) supplies loss_type & co.")
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--cpu-baseline", type=int, default=1)
+    p.add_argument("--cpu-batch", type=int, default=32)
+    return p.parse_args()
+
+
+def reference_config(prefix, model, global_batch, precision):
+    """The parsed reference YAML (tests/golden/configs.json, produced from /root/reference by oracle/make_golden.py) + overrides."""
+    from sparsify_clip_amd.config import finalize_config
+    with open(os.path.join(ROOT, "tests", "golden", "configs.json")) as f:
+        table = json.load(f)
+    key = [k for k in table if os.path.basename(k).startswith(prefix + "-")][0]
+    return key, finalize_config(table[key], 0, {"model": model, "batch_size": global_batch, "precision": precision, "log_every": 1 << 30})
+
+
+def gemm_roofline(model, device):
+    """Replay the bf16 NT GEMM launches of one training step (forward linears + activation-gradient GEMMs of both towers)
+    with a HIP event pair around each launch on the launch stream; algorithmic FLOPs = 2*M*N*K per launch."""
+    from sparsify_clip_amd import ops
+    launches = []
+    for tower in (model.visual, model.text):
+        rows, w = tower.batch * tower.seq, tower.width
+        shapes = [(rows, 3 * w, w), (rows, w, w), (rows, 4 * w, w), (rows, w, 4 * w),      # fwd: qkv, out, fc1, fc2
+                  (rows, w, 3 * w), (rows, w, w), (rows, w, 4 * w), (rows, 4 * w, w)]      # dX of the same four
+        launches += [(s, tower.layers) for s in shapes]
+    if model.k_pad == model.k_patch:
+        launches.append(((model.visual.batch * model.grid ** 2, model.cfg["v_width"], model.k_patch), 1))
+    total_flops, total_ms, count = 0.0, 0.0, 0
+    for (m, n, k), reps in launches:
+        a = torch.randn(m, k, device=device).to(torch.bfloat16)
+        b = torch.randn(n, k, device=device).to(torch.bfloat16)
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=device)
+        ops.gemm_bf16_nt(a, b, out=out)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for s, e in evs:
+            s.record()
+            ops.gemm_bf16_nt(a, b, out=out)
+            e.record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in evs)[1]
+        total_flops += 2.0 * m * n * k * reps
+        total_ms += ms * reps
+        count += reps
+        del a, b, out
+    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": count,
+            "avg_launch_us": round(total_ms * 1e3 / count, 1), "flops_per_launch_avg": total_flops / count}
+
+
+def cpu_baseline(cfg, model_name, batch):
+    """Oracle CPU step (plain torch fp32, the restatement pinned to the reference by tests/golden) on a bounded sample."""
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    torch.set_num_threads(os.cpu_count() or 1)
+    ref = create_model(model_name, seed=0)
+    c = dict(cfg, batch_size=batch)
+    tr = CpuTrainer(c, 100, model=ref)
+    tr.epoch = 1
+    images, tokens = synthetic_batch(1, batch, ref.cfg)
+    images, tokens = torch.tensor(images), torch.tensor(tokens)
+    tr.step(images, tokens)   # untimed first step (thread pool / allocator warm-up)
+    n = 2
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(images, tokens)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * n / dt, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full training steps of {model_name} fp32 at {batch} pairs/step (oracle/train_step.py, plain torch on the host cores)"}
+
+
+def main():
+    args = parse()
+    from sparsify_clip_amd import dist as D
+    rank, local_rank, world = D.init_process_group()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    from sparsify_clip_amd.data import synthetic_batch
+    from sparsify_clip_amd.train import Trainer
+    global_batch = args.local_batch * world
+    key, cfg = reference_config(args.experiment, args.model, global_batch, args.precision)
+    trainer = Trainer(cfg, device, steps_per_epoch=1000)
+    trainer.epoch = max(1, cfg["only_lunif_epochs"])       # main phase: the full loss stack, not the warm-up branch
+    c = trainer.model.cfg
+    batches = [tuple(t.to(device) for t in synthetic_batch(42 + rank + 100 * k, args.local_batch, c["image_size"], c["ctx"], c["vocab"])) for k in range(2)]
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(*batches[i % 2])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.step(*batches[i % 2])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = t.item()
+    last_loss = float(loss.item())
+    pairs_per_s = global_batch * args.steps / elapsed
+    out = {"metric": "image-text pairs/sec", "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": f"{os.path.basename(key)} main phase (anchor+lalign+lunif(centroids)), {args.model}, local batch {args.local_batch}/GPU, "
+                                  f"global batch {global_batch}, AdamW, random-init weights",
+                      "global_batch": global_batch, "local_batch": args.local_batch, "parallelism": f"dp{world}"},
+           "last_loss": last_loss,
+           "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
+    if rank == 0:
+        if args.precision == "bf16":
+            out["roofline"] = gemm_roofline(trainer.model, device)
+        if args.cpu_baseline and world == 1:
+            del trainer
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(cfg, args.model, args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""YAML experiment configs: the reference's schema, unchanged files, plus optional overrides.
+
+The reference reads a YAML into a dict and passes it everywhere (sparsify_clip.py:1134-1156): `learning_rate`
+arrives as a string ("1e-4") and is float()-ed (:1141), `device_id` is injected (:1139).  Every shipped YAML says
+model "RN50", batch 256, fp16 True; the BASELINE configurations need ViT-B/32 or ViT-L/14 at other batch sizes, so
+overrides are applied on top of the unchanged file.
+"""
+from __future__ import annotations
+
+import os
+
+import yaml
+
+from ._lib import ScError
+from .loss_dispatch import LOSS_TABLE, validate_loss_type
+
+REQUIRED_KEYS = ["project_name", "run_name", "seed", "learning_rate", "batch_size", "model", "num_train_samples", "num_test_samples",
+                 "epochs", "loss_type", "only_lunif_epochs", "anchor_temperature", "anchor_temperature_learnable",
+                 "save_checkpoint_every_n_epochs", "resume_checkpoint", "fp16"]
+# build-side keys (not in the reference schema); all default to "behave like the reference"
+EXTRA_DEFAULTS = {"precision": None, "synthetic": True, "eval_batch_size": None, "dp": 1, "log_every": 10, "steps_per_epoch": None}
+
+
+def load_config(path: str, device_id: int = 0, overrides: dict | None = None):
+    """One YAML file -> config dict, or None for an empty file (the reference crashes on all_experiments.yaml, :1152)."""
+    with open(path, "r") as f:
+        cfg = yaml.safe_load(f)
+    if cfg is None:
+        return None
+    return finalize_config(cfg, device_id, overrides)
+
+
+def finalize_config(cfg: dict, device_id: int = 0, overrides: dict | None = None):
+    cfg = dict(cfg)
+    for k, v in (overrides or {}).items():
+        if v is not None:
+            cfg[k] = v
+    missing = [k for k in REQUIRED_KEYS if k not in cfg]
+    if missing:
+        raise ScError(f"config is missing keys {missing}")
+    cfg["device_id"] = device_id                       # :1139
+    cfg["learning_rate"] = float(cfg["learning_rate"])  # :1141
+    spec = validate_loss_type(cfg["loss_type"])
+    if spec.use_beta and not {"beta_warmup_epoch", "beta_decay_epoch"} <= cfg.keys():
+        raise ScError(f"loss_type {cfg['loss_type']!r} needs beta_warmup_epoch and beta_decay_epoch")
+    if spec.use_alpha and not {"alpha_warmup_epoch", "alpha_increment_epoch"} <= cfg.keys():
+        raise ScError(f"loss_type {cfg['loss_type']!r} needs alpha_warmup_epoch and alpha_increment_epoch")
+    for k, v in EXTRA_DEFAULTS.items():
+        cfg.setdefault(k, v)
+    if cfg["precision"] is None:
+        cfg["precision"] = "bf16" if cfg["fp16"] else "fp32"   # bf16 replaces the reference's fp16 autocast + GradScaler
+    return cfg
+
+
+def config_files(path: str):
+    """A file, or every *.yaml in a directory (sorted; the reference uses unsorted os.listdir, :1147)."""
+    if os.path.isfile(path):
+        return [path]
+    if os.path.isdir(path):
+        return sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith(".yaml"))
+    raise ScError(f"config path {path!r} does not exist")
+
+
+__all__ = ["load_config", "finalize_config", "config_files", "LOSS_TABLE", "REQUIRED_KEYS"]

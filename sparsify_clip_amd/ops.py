@@ -1,0 +1,307 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of include/sparsify_hip.h).
+
+Every wrapper takes CUDA(ROCm) tensors, enqueues on the current stream and returns tensors; nothing here
+computes on the host and nothing falls back to torch when the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import LIB, SC_BF16, SC_F32, BlockDesc, GemmEpilogue, ScError, ptr, require_gpu, sc_dtype, stream_ptr
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """Grow-only byte workspace per (device, tag); reused across calls on the same stream."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def make_epilogue(alpha=1.0, beta=0.0, bias=None, pre_out=None, act=0, resid=None, dgelu_pre=None, ld_aux=0):
+    e = GemmEpilogue()
+    e.alpha, e.beta, e.act = float(alpha), float(beta), int(act)
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.pre_out = pre_out.data_ptr() if pre_out is not None else None
+    e.resid = resid.data_ptr() if resid is not None else None
+    e.resid_dtype = sc_dtype(resid.dtype) if resid is not None else SC_F32
+    e.dgelu_pre = dgelu_pre.data_ptr() if dgelu_pre is not None else None
+    e.ld_aux = int(ld_aux)
+    e._keepalive = (bias, pre_out, resid, dgelu_pre)   # the struct only holds raw pointers
+    return e
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_f32(a, b, trans_a=False, trans_b=False, out=None, epi: GemmEpilogue | None = None):
+    require_gpu(a, "a", torch.float32), require_gpu(b, "b", torch.float32)
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    kb = b.shape[1] if trans_b else b.shape[0]
+    if kb != k:
+        raise ScError(f"gemm_f32: inner dimensions differ ({k} vs {kb})")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    LIB.call("sc_gemm_f32", int(trans_a), int(trans_b), m, n, k, ptr(a), a.shape[1], ptr(b), b.shape[1], ptr(out), out.shape[1],
+             ctypes.byref(epi) if epi is not None else None, stream_ptr())
+    return out
+
+
+def gemm_bf16_nt(a, b, out_dtype=torch.bfloat16, out=None, epi: GemmEpilogue | None = None):
+    require_gpu(a, "a", torch.bfloat16), require_gpu(b, "b", torch.bfloat16)
+    m, k = a.shape
+    n = b.shape[0]
+    if out is None:
+        out = torch.empty(m, n, dtype=out_dtype, device=a.device)
+    LIB.call("sc_gemm_bf16_nt", m, n, k, ptr(a), k, ptr(b), b.shape[1], ptr(out), n, sc_dtype(out.dtype),
+             ctypes.byref(epi) if epi is not None else None, stream_ptr())
+    return out
+
+
+def gemm_bf16_tn(a, b, out=None, alpha=1.0, beta=0.0):
+    """out[M,N] = alpha * a[R,M]^T b[R,N] + beta*out (fp32)."""
+    require_gpu(a, "a", torch.bfloat16), require_gpu(b, "b", torch.bfloat16)
+    r, m = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.zeros(m, n, dtype=torch.float32, device=a.device)
+    nbytes = LIB.raw("sc_gemm_bf16_tn_workspace_bytes")(m, n, r)
+    ws = _workspace(nbytes, a.device)
+    LIB.call("sc_gemm_bf16_tn", m, n, r, ptr(a), m, ptr(b), n, ptr(out), n, float(alpha), float(beta), ptr(ws), ws.numel(), stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ loss head
+def _loss_ws(b, e, device):
+    n = LIB.raw("sc_loss_workspace_bytes")(b, e)
+    return _workspace(n, device, "loss")
+
+
+def contrastive_fwd_bwd(img, txt, temperature, grad_scale=1.0, need_grad=True, need_dtemp=False):
+    require_gpu(img, "img", torch.float32), require_gpu(txt, "txt", torch.float32)
+    b, e = img.shape
+    ws = _loss_ws(b, e, img.device)
+    loss = torch.empty(1, dtype=torch.float32, device=img.device)
+    d_img = torch.empty_like(img) if need_grad else None
+    d_txt = torch.empty_like(txt) if need_grad else None
+    d_temp = torch.empty(1, dtype=torch.float32, device=img.device) if (need_grad and need_dtemp) else None
+    LIB.call("sc_contrastive_fwd_bwd", ptr(img), ptr(txt), b, e, float(temperature), float(grad_scale), ptr(loss), ptr(d_img), ptr(d_txt),
+             ptr(d_temp), ptr(ws), ws.numel(), stream_ptr())
+    return loss, d_img, d_txt, d_temp
+
+
+def lunif_fwd_bwd(x, t=2.0, grad_scale=1.0, need_grad=True):
+    require_gpu(x, "x", torch.float32)
+    b, e = x.shape
+    ws = _loss_ws(b, e, x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if need_grad else None
+    LIB.call("sc_lunif_fwd_bwd", ptr(x), b, e, float(t), float(grad_scale), ptr(loss), ptr(dx), ptr(ws), ws.numel(), stream_ptr())
+    return loss, dx
+
+
+def lalign_fwd_bwd(x, y, alpha=2.0, grad_scale=1.0, need_grad=True):
+    require_gpu(x, "x", torch.float32), require_gpu(y, "y", torch.float32)
+    b, e = x.shape
+    ws = _loss_ws(b, e, x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if need_grad else None
+    dy = torch.empty_like(y) if need_grad else None
+    LIB.call("sc_lalign_fwd_bwd", ptr(x), ptr(y), b, e, float(alpha), float(grad_scale), ptr(loss), ptr(dx), ptr(dy), ptr(ws), ws.numel(),
+             stream_ptr())
+    return loss, dx, dy
+
+
+def sparsify_fwd_bwd(x, grad_scale=1.0, need_grad=True):
+    require_gpu(x, "x", torch.float32)
+    b, e = x.shape
+    ws = _loss_ws(b, e, x.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if need_grad else None
+    LIB.call("sc_sparsify_fwd_bwd", ptr(x), b, e, float(grad_scale), ptr(loss), ptr(dx), ptr(ws), ws.numel(), stream_ptr())
+    return loss, dx
+
+
+def l2norm_fwd(x, eps=0.0):
+    require_gpu(x, "x", torch.float32)
+    b, e = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty(b, dtype=torch.float32, device=x.device)
+    LIB.call("sc_l2norm_fwd", ptr(x), b, e, float(eps), ptr(y), ptr(inv), stream_ptr())
+    return y, inv
+
+
+def l2norm_bwd(y, inv, dy):
+    require_gpu(dy, "dy", torch.float32)
+    dx = torch.empty_like(y)
+    LIB.call("sc_l2norm_bwd", ptr(y), ptr(inv), ptr(dy), y.shape[0], y.shape[1], ptr(dx), stream_ptr())
+    return dx
+
+
+def centroid_fwd(a, b):
+    require_gpu(a, "a", torch.float32), require_gpu(b, "b", torch.float32)
+    c = torch.empty_like(a)
+    inv = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    LIB.call("sc_centroid_fwd", ptr(a), ptr(b), a.shape[0], a.shape[1], ptr(c), ptr(inv), stream_ptr())
+    return c, inv
+
+
+def centroid_bwd_accumulate(c, inv, dc, d_a, d_b):
+    LIB.call("sc_centroid_bwd", ptr(c), ptr(inv), ptr(dc), c.shape[0], c.shape[1], ptr(d_a), ptr(d_b), stream_ptr())
+
+
+def axpy_(y, alpha, x):
+    LIB.call("sc_axpy_f32", y.numel(), float(alpha), ptr(x), ptr(y), stream_ptr())
+    return y
+
+
+def retrieval_ranks(score):
+    require_gpu(score, "score", torch.float32)
+    n = score.shape[0]
+    outs = [torch.empty(n, dtype=torch.int32, device=score.device) for _ in range(4)]
+    LIB.call("sc_retrieval_ranks", ptr(score), n, *[ptr(o) for o in outs], stream_ptr())
+    return outs  # rank_fwd, rank_bwd, top1_fwd, top1_bwd
+
+
+# ------------------------------------------------------------------------------------------------ encoder pieces
+def layernorm_fwd(x, gamma, beta, out_dtype, out=None):
+    require_gpu(x, "x", torch.float32)
+    rows, w = x.shape
+    y = out if out is not None else torch.empty(rows, w, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    LIB.call("sc_layernorm_fwd", ptr(x), rows, w, ptr(gamma), ptr(beta), ptr(y), sc_dtype(out_dtype), ptr(mean), ptr(rstd), stream_ptr())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_cast=False, dgamma=None, dbeta=None, accumulate=False):
+    rows, w = x.shape
+    dx = torch.empty_like(x)
+    dx_cast = torch.empty(rows, w, dtype=dy.dtype, device=x.device) if want_cast else None
+    if dgamma is None:
+        dgamma = torch.zeros(w, dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(w, dtype=torch.float32, device=x.device)
+    ws = _workspace(256 * 2 * w * 4, x.device)
+    LIB.call("sc_layernorm_bwd", ptr(dy), sc_dtype(dy.dtype), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), rows, w, ptr(dres), ptr(dx), ptr(dx_cast),
+             ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
+    return dx, dx_cast, dgamma, dbeta
+
+
+def attention_fwd(qkv, batch, seq, heads, causal):
+    rows, w3 = qkv.shape
+    w = w3 // 3
+    out = torch.empty(rows, w, dtype=qkv.dtype, device=qkv.device)
+    LIB.call("sc_attention_fwd", ptr(qkv), ptr(out), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
+    return out
+
+
+def attention_bwd(qkv, d_out, batch, seq, heads, causal):
+    w = qkv.shape[1] // 3
+    d_qkv = torch.empty_like(qkv)
+    LIB.call("sc_attention_bwd", ptr(qkv), ptr(d_out), ptr(d_qkv), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
+    return d_qkv
+
+
+def colsum(x, out=None, accumulate=False):
+    rows, n = x.shape
+    if out is None:
+        out = torch.zeros(n, dtype=torch.float32, device=x.device)
+    ws = _workspace(256 * n * 4, x.device)
+    LIB.call("sc_colsum", ptr(x), sc_dtype(x.dtype), rows, n, n, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
+    return out
+
+
+def im2col(images, patch, kpad, out_dtype):
+    require_gpu(images, "images", torch.float32)
+    b, _, res, _ = images.shape
+    g = res // patch
+    out = torch.empty(b * g * g, kpad, dtype=out_dtype, device=images.device)
+    LIB.call("sc_im2col", ptr(images), b, res, patch, kpad, ptr(out), sc_dtype(out_dtype), stream_ptr())
+    return out
+
+
+def vit_tokens_fwd(patch_out, cls, pos, batch, seq):
+    w = patch_out.shape[1]
+    x = torch.empty(batch * seq, w, dtype=torch.float32, device=patch_out.device)
+    LIB.call("sc_vit_tokens_fwd", ptr(patch_out), sc_dtype(patch_out.dtype), ptr(cls), ptr(pos), batch, seq, w, ptr(x), stream_ptr())
+    return x
+
+
+def vit_tokens_bwd(dx, batch, seq, out_dtype, d_cls, d_pos, accumulate):
+    w = dx.shape[1]
+    d_patch = torch.empty(batch * (seq - 1), w, dtype=out_dtype, device=dx.device)
+    LIB.call("sc_vit_tokens_bwd", ptr(dx), batch, seq, w, ptr(d_patch), sc_dtype(out_dtype), ptr(d_cls), ptr(d_pos), int(accumulate), stream_ptr())
+    return d_patch
+
+
+def text_embed_fwd(tokens, tok_emb, pos, out=None):
+    require_gpu(tokens, "tokens", torch.int64)
+    b, s = tokens.shape
+    vocab, w = tok_emb.shape
+    x = out if out is not None else torch.empty(b * s, w, dtype=torch.float32, device=tokens.device)
+    LIB.call("sc_text_embed_fwd", ptr(tokens), ptr(tok_emb), ptr(pos), b, s, w, vocab, ptr(x), stream_ptr())
+    return x
+
+
+def text_embed_bwd(dx, sorted_tokens, order, batch, seq, d_tok_emb, d_pos, accumulate):
+    vocab, w = d_tok_emb.shape
+    LIB.call("sc_text_embed_bwd", ptr(dx), ptr(sorted_tokens), ptr(order), order.numel(), batch, seq, w, vocab, ptr(d_tok_emb), ptr(d_pos),
+             int(accumulate), stream_ptr())
+
+
+def argmax_tokens(tokens):
+    b, s = tokens.shape
+    eot = torch.empty(b, dtype=torch.int32, device=tokens.device)
+    LIB.call("sc_argmax_tokens", ptr(tokens), b, s, ptr(eot), stream_ptr())
+    return eot
+
+
+def pool_gather(x, idx, batch, seq):
+    w = x.shape[1]
+    out = torch.empty(batch, w, dtype=torch.float32, device=x.device)
+    LIB.call("sc_pool_gather", ptr(x), ptr(idx), batch, seq, w, ptr(out), stream_ptr())
+    return out
+
+
+def pool_scatter(d_out, idx, batch, seq, dx):
+    """dx must be zeroed by the caller."""
+    LIB.call("sc_pool_scatter", ptr(d_out), ptr(idx), batch, seq, d_out.shape[1], ptr(dx), stream_ptr())
+    return dx
+
+
+def cast_bf16(src, dst=None):
+    require_gpu(src, "src", torch.float32)
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    LIB.call("sc_cast_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream_ptr())
+    return dst
+
+
+def transpose_cast_bf16(src, dst=None):
+    rows, cols = src.shape
+    if dst is None:
+        dst = torch.empty(cols, rows, dtype=torch.bfloat16, device=src.device)
+    LIB.call("sc_transpose_cast_bf16", ptr(src), rows, cols, ptr(dst), stream_ptr())
+    return dst
+
+
+def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    LIB.call("sc_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+             float(weight_decay), int(step), float(grad_scale), stream_ptr())
+
+
+def block_workspace_bytes(rows, width, mlp_width, dtype) -> int:
+    return LIB.raw("sc_block_workspace_bytes")(rows, width, mlp_width, sc_dtype(dtype))
+
+
+def block_fwd(desc: BlockDesc):
+    LIB.call("sc_block_fwd", ctypes.byref(desc), stream_ptr())
+
+
+def block_bwd(desc: BlockDesc, dx_out, dx_out_t, dx_in, dx_in_t):
+    LIB.call("sc_block_bwd", ctypes.byref(desc), ptr(dx_out), ptr(dx_out_t), ptr(dx_in), ptr(dx_in_t), stream_ptr())

@@ -1,0 +1,217 @@
+"""Experiment runner: the reference's main / train_model / evaluate_model surface (sparsify_clip.py:534-676,
+:682-986, :1071-1121) re-created for one process per GPU on the HIP library.
+
+Step order, optimiser hyper-parameters, schedule inputs (1-based current_batch, lr = 0 on the first step when
+there is no warm-up phase), phase switch on `epoch < only_lunif_epochs`, checkpoint names and logged keys follow the
+reference; wandb is replaced by a local JSONL sink with the same keys, and the per-step `loss.item()` host sync
+(:944) by a deferred read-back every `log_every` steps.
+Deviations forced by the BASELINE batch sizes: the eval loader has its own batch size
+(`eval_batch_size`, default min(batch_size, num_test_samples)), and directories are created before saving.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import dist as D
+from . import ops
+from . import uniformity as U
+from ._lib import ScError
+from .data import SyntheticLoader, get_tokenizer
+from .loss_dispatch import step_loss, validate_loss_type
+from .model import create_model_and_transforms
+from .optim import AdamW
+from .schedules import get_cosine_schedule_with_warmup
+
+
+class JsonlLogger:
+    """wandb stand-in: one JSON object per log call, same keys as the reference (:659-667, :943-951)."""
+
+    def __init__(self, path=None):
+        self.path, self.rows = path, []
+        if path:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+
+    def log(self, row: dict):
+        self.rows.append(row)
+        if self.path:
+            with open(self.path, "a") as f:
+                f.write(json.dumps(row) + "\n")
+
+
+def set_seed(seed: int):
+    """Reference :1071-1078 (cudnn flags have no counterpart here: every kernel of the library is deterministic)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class Trainer:
+    """State of one training run; `step(images, captions_or_tokens)` is the hot path (reference :753-969)."""
+
+    def __init__(self, config, device, steps_per_epoch, logger=None, model=None):
+        validate_loss_type(config["loss_type"])
+        self.config, self.device = config, torch.device(device)
+        self.logger = logger or JsonlLogger(None)
+        self.model = model or create_model_and_transforms(config["model"], pretrained=None, device=self.device, precision=config["precision"],
+                                                          seed=config["seed"])[0]
+        self.tokenizer = get_tokenizer(config["model"], self.model.cfg["ctx"], self.model.cfg["vocab"])
+        self.model.train()
+        self.temperature = config["anchor_temperature"]
+        self.learnable_t = bool(config["anchor_temperature_learnable"])
+        extra = []
+        if self.learnable_t:   # :716-717 - a 0-dim fp32 parameter that the reference leaves on the CPU
+            self.temperature = torch.nn.Parameter(torch.tensor(self.temperature, dtype=torch.float32), requires_grad=True)
+            extra = [self.temperature]
+        self.sync = D.GradSync(self.model)
+        D.broadcast_parameters(self.model)
+        self.optimizer = AdamW(self.model, lr=config["learning_rate"], extra_params=extra)          # :730 (torch defaults)
+        self.t_total = steps_per_epoch * config["epochs"]                                          # :734
+        self.scheduler = get_cosine_schedule_with_warmup(self.optimizer, int(0.20 * self.t_total), self.t_total, config=config)  # :735-736
+        self.current_batch, self.epoch = 0, 0
+        self.beta, self.alpha = 0.0, 0.0    # :743-744
+        self.pending_logs = []
+
+    def step(self, images, captions):
+        cfg, m = self.config, self.model
+        self.current_batch += 1                                                    # :755
+        tokens = captions if isinstance(captions, torch.Tensor) else self.tokenizer(captions)   # :762
+        img_e = m.image_forward(images)                                            # :768
+        txt_e = m.text_forward(tokens)                                             # :769
+        img_n, inv_i = ops.l2norm_fwd(img_e, 0.0)                                  # :772
+        txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0)                                  # :773
+        img_all, txt_all = D.all_gather_embeddings(img_n, txt_n)
+        temp = float(self.temperature.detach()) if self.learnable_t else float(self.temperature)
+        res = step_loss(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)   # :778-938
+        if res.beta is not None:
+            self.beta = res.beta
+        if res.alpha is not None:
+            self.alpha = res.alpha
+        row = {"learning_rate": self.scheduler.get_last_lr()[0]}
+        if self.learnable_t:
+            row["constrantive_temperature_learnable"] = temp                      # [sic] :945
+        else:
+            row.update(beta=self.beta, alpha=self.alpha)
+        self.pending_logs.append((res.loss, row))
+        self.optimizer.zero_grad()                                                 # :957
+        d_img_e = ops.l2norm_bwd(img_n, inv_i, D.local_rows(res.d_img))
+        d_txt_e = ops.l2norm_bwd(txt_n, inv_t, D.local_rows(res.d_txt))
+        m.image_backward(d_img_e)                                                  # :965
+        m.text_backward(d_txt_e)
+        if self.learnable_t and res.d_temp is not None:
+            self.temperature.grad = res.d_temp.detach().cpu().reshape(())
+        self.sync.wait_all()
+        self.optimizer.step()                                                      # :966
+        self.scheduler.step()                                                      # :969
+        if len(self.pending_logs) >= cfg.get("log_every", 10):
+            self.flush_logs()
+        return res.loss
+
+    def flush_logs(self):
+        for loss, row in self.pending_logs:
+            self.logger.log({"train_loss": float(loss.item()), **row})
+        self.pending_logs = []
+
+
+def evaluate_model(model, test_loader, device, plot_embeddings=False, logger=None, tokenizer=None):
+    """Retrieval + geometry metrics with the reference's keys (:534-676).  Plots (UMAP/t-SNE/PCA, :599-620) are out of scope."""
+    was_training = model.training
+    model.eval()
+    tokenizer = tokenizer or get_tokenizer(model.name, model.cfg["ctx"], model.cfg["vocab"])
+    imgs, txts = [], []
+    with torch.no_grad():
+        for images, captions in test_loader:
+            tokens = captions if isinstance(captions, torch.Tensor) else tokenizer(captions)
+            imgs.append(model.image_forward(images).clone())
+            txts.append(model.text_forward(tokens).clone())
+    if not imgs:
+        raise ScError("evaluation loader yielded no batches (the reference's drop_last loader does this when "
+                      "batch_size > num_test_samples; set eval_batch_size)")
+    img, _ = ops.l2norm_fwd(torch.cat(imgs), 0.0)       # :624-625
+    txt, _ = ops.l2norm_fwd(torch.cat(txts), 0.0)
+    score = ops.gemm_f32(txt, img, trans_b=True)        # [N_text, N_image]  :628
+    rank_f, rank_b, top_f, top_b = ops.retrieval_ranks(score)
+    n = score.shape[0]
+
+    def recall(rank, prefix):
+        r = [(rank < k).sum().item() / n for k in (1, 5, 10)]
+        return {f"{prefix}_r1": round(r[0] * 100, 4), f"{prefix}_r5": round(r[1] * 100, 4), f"{prefix}_r10": round(r[2] * 100, 4),
+                f"{prefix}_ravg": round(sum(r) / 3 * 100, 4)}
+
+    final_log = {**recall(rank_f, "forward"), **recall(rank_b, "backward"),
+                 "gap": round(U.compute_gap(img, txt), 4),
+                 "mean_angular_value_image": round(U.compute_mean_angular_value_of_a_modality(img), 4),
+                 "mean_angular_value_text": round(U.compute_mean_angular_value_of_a_modality(txt), 4),
+                 "uniformity": round(U.uniformity(img, txt), 4),
+                 "mean_cosine_similarity_true_pairs": round(U.mean_distance_of_true_pairs(img, txt), 4)}
+    if logger is not None:
+        logger.log(final_log)
+    model.train(was_training)
+    return final_log
+
+
+def dataset_loader(config, device):
+    """Synthetic stand-in for the reference's COCO loaders (:992-1065): same (train, test) pair, drop_last semantics."""
+    world, rank = D.world_size(), D.get_rank()
+    gb = config["batch_size"]
+    if gb % world:
+        raise ScError(f"batch_size {gb} is not divisible by the {world} data-parallel ranks")
+    n_train = config["num_train_samples"] if config["num_train_samples"] != -1 else 118287   # COCO train2017
+    if config.get("steps_per_epoch"):
+        n_train = config["steps_per_epoch"] * gb
+    n_test = config["num_test_samples"] if config["num_test_samples"] != -1 else 5000
+    eb = config.get("eval_batch_size") or min(gb, n_test)
+    from .model import CONFIGS, canonical_name
+    c = CONFIGS[canonical_name(config["model"])]
+    train = SyntheticLoader(n_train // world, gb // world, config["seed"] + 1000 * rank, device, c["image_size"], c["ctx"], c["vocab"])
+    test = SyntheticLoader(n_test, eb, config["seed"] + 777, device, c["image_size"], c["ctx"], c["vocab"], distinct=max(1, n_test // eb))
+    return train, test
+
+
+def train_model(config, train_loader, test_loader, device, logger=None):
+    """Reference :682-986."""
+    trainer = Trainer(config, device, len(train_loader), logger)
+    model = trainer.model
+    start_epoch = 0
+    if config["resume_checkpoint"]:   # :719-724 (weights only, `module.`-prefixed keys accepted)
+        model.load_state_dict(torch.load(config["resume_checkpoint"], map_location="cpu", weights_only=True))
+        start_epoch = config.get("resume_epoch", 0)
+    if len(train_loader) == 0:
+        raise ScError("training loader yields no batches (num_train_samples < batch_size with drop_last, SURVEY 0.10)")
+    evaluate_model(model, test_loader, device, logger=logger)   # :740
+    for epoch in range(start_epoch, start_epoch + config["epochs"]):
+        trainer.epoch = epoch
+        for images, captions in train_loader:
+            trainer.step(images, captions)
+        trainer.flush_logs()
+        evaluate_model(model, test_loader, device, logger=logger)   # :980
+        if (epoch + 1) % config["save_checkpoint_every_n_epochs"] == 0 and D.get_rank() == 0:   # :982-984
+            os.makedirs("models", exist_ok=True)
+            torch.save(model.state_dict(prefix="module."), f"models/{config['run_name']}_epoch_{epoch + 1}.pt")
+    return model
+
+
+def main(config):
+    """Reference :1084-1121 (wandb.init/save/finish -> JSONL under logs/)."""
+    logger = JsonlLogger(os.path.join("logs", f"{config['run_name']}.jsonl")) if D.get_rank() == 0 else JsonlLogger(None)
+    set_seed(config["seed"])
+    if not torch.cuda.is_available():
+        raise ScError("no GPU visible: this runner has no CPU path (the reference falls back to CPU at :1100; the oracle/ "
+                      "directory holds the CPU restatement used for parity tests)")
+    device = torch.device("cuda", config["device_id"])
+    torch.cuda.set_device(device)
+    train_loader, test_loader = dataset_loader(config, device)
+    t0 = time.time()
+    model = train_model(config, train_loader, test_loader, device, logger)
+    final_log = evaluate_model(model, test_loader, device, logger=logger)
+    if D.get_rank() == 0:
+        os.makedirs("models", exist_ok=True)
+        torch.save(model.state_dict(prefix="module."), "models/" + config["run_name"] + ".pt")   # :1118
+    return {"final": final_log, "seconds": time.time() - t0}

@@ -1,0 +1,422 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against a CPU reference (fp64 where cheap).
+
+Tolerances: fp32 kernels (MFMA f32 = fmaf chain) rel 1e-5..1e-4 on values; bf16 kernels are compared with the
+same computation on bf16-ROUNDED inputs in fp64, so only accumulation order and the output rounding differ.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sparsify_clip_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def assert_close(got, want, rtol, atol, what=""):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        idx = bad.nonzero()[:5].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} elements off, max abs err {err.max():.3e} "
+                             f"(want max {want.abs().max():.3e}), first bad idx {idx}, "
+                             f"got {[got[tuple(i)].item() for i in idx]} want {[want[tuple(i)].item() for i in idx]}, "
+                             f"nonfinite {int((~torch.isfinite(got)).sum())}")
+
+
+def gelu64(x):
+    return 0.5 * x * (1 + torch.erf(x / np.sqrt(2.0)))
+
+
+def gelu_grad64(x):
+    return 0.5 * (1 + torch.erf(x / np.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)
+
+
+# ------------------------------------------------------------------------------------------------ fp32 GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(200, 136, 75), (256, 384, 512), (33, 515, 1030)])
+def test_gemm_f32_orientations(ops, ta, tb, m, n, k):
+    a = rnd(k, m, seed=1) if ta else rnd(m, k, seed=1)
+    b = rnd(n, k, seed=2) if tb else rnd(k, n, seed=2)
+    want = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    got = ops.gemm_f32(a.to(DEV), b.to(DEV), trans_a=bool(ta), trans_b=bool(tb))
+    assert_close(got, want, 1e-5, 1e-5 * np.sqrt(k), f"gemm_f32 ta={ta} tb={tb}")
+
+
+def test_gemm_f32_epilogue(ops):
+    m, n, k = 130, 260, 96
+    a, w, bias, resid, pre = rnd(m, k, seed=3), rnd(n, k, seed=4), rnd(n, seed=5), rnd(m, n, seed=6), rnd(m, n, seed=7)
+    acc = a.double() @ w.double().t()
+    # forward-style: bias + gelu + residual, pre-activation kept
+    pre_out = torch.empty(m, n, device=DEV)
+    e = ops.make_epilogue(alpha=0.5, bias=bias.to(DEV), pre_out=pre_out, act=1, resid=resid.to(DEV), ld_aux=n)
+    got = ops.gemm_f32(a.to(DEV), w.to(DEV), trans_b=True, epi=e)
+    v = 0.5 * acc + bias.double()
+    assert_close(pre_out, v, 1e-5, 1e-4, "pre_out")
+    assert_close(got, gelu64(v) + resid.double(), 1e-5, 1e-4, "bias+gelu+resid")
+    # backward-style: multiply by gelu'(pre), accumulate into C
+    c0 = rnd(m, n, seed=8)
+    out = c0.to(DEV).clone()
+    e = ops.make_epilogue(beta=1.0, dgelu_pre=pre.to(DEV), ld_aux=n)
+    ops.gemm_f32(a.to(DEV), w.to(DEV), trans_b=True, out=out, epi=e)
+    assert_close(out, acc * gelu_grad64(pre.double()) + c0.double(), 1e-5, 1e-4, "dgelu+beta")
+
+
+# ------------------------------------------------------------------------------------------------ bf16 GEMMs
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (300, 192, 128), (1024, 768, 768), (77, 2304, 512)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_nt(ops, m, n, k, out_dtype):
+    a, b = rnd(m, k, seed=11, dtype=torch.bfloat16), rnd(n, k, seed=12, dtype=torch.bfloat16)
+    want = a.double() @ b.double().t()
+    got = ops.gemm_bf16_nt(a.to(DEV), b.to(DEV), out_dtype=out_dtype)
+    rt = 1e-2 if out_dtype == torch.bfloat16 else 1e-4
+    assert_close(got, want, rt, 2e-3 * np.sqrt(k), f"gemm_bf16_nt {m}x{n}x{k}")
+
+
+def test_gemm_bf16_nt_asymmetric_identity(ops):
+    """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)."""
+    n, k = 256, 128
+    a = torch.eye(k, dtype=torch.bfloat16)
+    b = (torch.arange(n)[:, None] * 1.0 + torch.arange(k)[None, :] * 0.25).to(torch.bfloat16)
+    got = ops.gemm_bf16_nt(a.to(DEV), b.to(DEV), out_dtype=torch.float32)
+    assert_close(got, b.double().t(), 0, 1e-6, "identity x B^T")
+
+
+def test_gemm_bf16_nt_epilogue(ops):
+    m, n, k = 200, 256, 192
+    a, w = rnd(m, k, seed=13, dtype=torch.bfloat16), rnd(n, k, seed=14, scale=0.1, dtype=torch.bfloat16)
+    bias, resid = rnd(n, seed=15), rnd(m, n, seed=16)
+    acc = a.double() @ w.double().t()
+    pre_out = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    e = ops.make_epilogue(bias=bias.to(DEV), pre_out=pre_out, act=1, ld_aux=n)
+    got = ops.gemm_bf16_nt(a.to(DEV), w.to(DEV), epi=e)
+    v = acc + bias.double()
+    assert_close(pre_out, v, 1e-2, 1e-2, "bf16 pre_out")
+    assert_close(got, gelu64(v), 1e-2, 1e-2, "bf16 gelu")
+    e = ops.make_epilogue(bias=bias.to(DEV), resid=resid.to(DEV), ld_aux=n)
+    got = ops.gemm_bf16_nt(a.to(DEV), w.to(DEV), out_dtype=torch.float32, epi=e)
+    assert_close(got, v + resid.double(), 1e-4, 2e-3, "fp32 out + resid")
+    pre = rnd(m, n, seed=17, dtype=torch.bfloat16)
+    e = ops.make_epilogue(dgelu_pre=pre.to(DEV), ld_aux=n)
+    got = ops.gemm_bf16_nt(a.to(DEV), w.to(DEV), epi=e)
+    assert_close(got, acc * gelu_grad64(pre.double()), 1e-2, 1e-2, "bf16 dgelu")
+
+
+@pytest.mark.parametrize("r,m,n", [(64, 128, 128), (200, 136, 264), (4096, 768, 768), (1600, 2304, 768)])
+def test_gemm_bf16_tn(ops, r, m, n):
+    a, b = rnd(r, m, seed=21, dtype=torch.bfloat16), rnd(r, n, seed=22, dtype=torch.bfloat16)
+    want = a.double().t() @ b.double()
+    got = ops.gemm_bf16_tn(a.to(DEV), b.to(DEV))
+    assert_close(got, want, 1e-4, 2e-3 * np.sqrt(r), f"gemm_bf16_tn r={r}")
+    c0 = rnd(m, n, seed=23)
+    out = c0.to(DEV).clone()
+    ops.gemm_bf16_tn(a.to(DEV), b.to(DEV), out=out, alpha=0.5, beta=1.0)
+    assert_close(out, 0.5 * want + c0.double(), 1e-4, 2e-3 * np.sqrt(r), "tn alpha/beta")
+
+
+def test_gemm_bf16_tn_asymmetric(ops):
+    r, m, n = 64, 128, 128
+    a = torch.zeros(r, m, dtype=torch.bfloat16)
+    a[torch.arange(r), torch.arange(r)] = 1.0          # A^T picks rows of B
+    b = (torch.arange(r)[:, None] * 1.0 + torch.arange(n)[None, :] * 0.5).to(torch.bfloat16)
+    got = ops.gemm_bf16_tn(a.to(DEV), b.to(DEV))
+    want = a.double().t() @ b.double()
+    assert_close(got, want, 0, 1e-6, "tn selector")
+
+
+# ------------------------------------------------------------------------------------------------ loss head
+def _oracle():
+    from oracle import loss_head as L
+    return L
+
+
+@pytest.mark.parametrize("tag", ["rand32x512", "clustered64x768"])
+def test_loss_head_small_golden(ops, golden_small, tag):
+    arr, meta = golden_small
+    v = meta[tag]["values"]
+    img, txt = torch.tensor(arr[f"{tag}/img"]).to(DEV), torch.tensor(arr[f"{tag}/txt"]).to(DEV)
+    R = 1e-4  # north_star: per-step loss within 1e-4 relative of the reference fp32 CPU path
+    loss, di, dt, dtemp = ops.contrastive_fwd_bwd(img, txt, 0.1, need_dtemp=True)
+    assert abs(loss.item() - v["contrastive_T0.1"]) <= R * abs(v["contrastive_T0.1"])
+    assert_close(di, torch.tensor(arr[f"{tag}/contrastive_T0.1.g0"]), 1e-3, 1e-7, "contrastive d_img")
+    assert_close(dt, torch.tensor(arr[f"{tag}/contrastive_T0.1.g1"]), 1e-3, 1e-7, "contrastive d_txt")
+    assert abs(dtemp.item() - v["contrastive_learnableT.g2.value"]) <= 1e-3 * abs(v["contrastive_learnableT.g2.value"])
+    loss, _, _, _ = ops.contrastive_fwd_bwd(img, txt, 0.07, need_grad=False)
+    assert abs(loss.item() - v["contrastive_T0.07"]) <= R * abs(v["contrastive_T0.07"])
+    loss, dx = ops.lunif_fwd_bwd(img, 2.0)
+    assert abs(loss.item() - v["lunif_img"]) <= R * abs(v["lunif_img"])
+    assert_close(dx, torch.tensor(arr[f"{tag}/lunif_img.g0"]), 2e-3, 2e-7, "lunif d_img")
+    loss, dx = ops.lunif_fwd_bwd(txt, 3.0)
+    assert abs(loss.item() - v["lunif_txt_t3"]) <= R * abs(v["lunif_txt_t3"])
+    assert_close(dx, torch.tensor(arr[f"{tag}/lunif_txt_t3.g0"]), 2e-3, 2e-7, "lunif t=3 d_txt")
+    loss, dx, dy = ops.lalign_fwd_bwd(img, txt, 2.0)
+    assert abs(loss.item() - v["lalign"]) <= R * abs(v["lalign"])
+    assert_close(dx, torch.tensor(arr[f"{tag}/lalign.g0"]), 1e-4, 1e-8, "lalign dx")
+    assert_close(dy, torch.tensor(arr[f"{tag}/lalign.g1"]), 1e-4, 1e-8, "lalign dy")
+    loss, dx, _ = ops.lalign_fwd_bwd(img, txt, 1.0)
+    assert abs(loss.item() - v["lalign_alpha1"]) <= R * abs(v["lalign_alpha1"])
+    assert_close(dx, torch.tensor(arr[f"{tag}/lalign_alpha1.g0"]), 1e-4, 1e-8, "lalign alpha=1 dx")
+    loss, dx = ops.sparsify_fwd_bwd(img)
+    assert abs(loss.item() - v["sparsify_img"]) <= R * abs(v["sparsify_img"])
+    assert_close(dx, torch.tensor(arr[f"{tag}/sparsify_img.g0"]), 1e-3, 1e-7, "sparsify dx")
+    # centroids: normalize((a+b)/2) -> lunif -> back to a and b
+    c, inv = ops.centroid_fwd(img, txt)
+    loss, dc = ops.lunif_fwd_bwd(c, 2.0)
+    assert abs(loss.item() - v["lunif_centroids"]) <= R * abs(v["lunif_centroids"])
+    da, db = torch.zeros_like(img), torch.zeros_like(txt)
+    ops.centroid_bwd_accumulate(c, inv, dc, da, db)
+    assert_close(da, torch.tensor(arr[f"{tag}/lunif_centroids.g0"]), 2e-3, 2e-7, "centroid d_img")
+    assert_close(db, torch.tensor(arr[f"{tag}/lunif_centroids.g1"]), 2e-3, 2e-7, "centroid d_txt")
+
+
+@pytest.mark.parametrize("key", ["b512_d512_rand", "b4096_d512_rand", "b8192_d512_rand", "b4096_d768_rand", "b2048_d512_clustered"])
+def test_loss_head_large_golden(ops, golden_large, key):
+    """BASELINE sizes: inputs regenerated from the Philox seed, reference outputs from the fixture."""
+    L = _oracle()
+    g = golden_large[key]
+    v = g["values"]
+    img_np, txt_np = L.philox_embeddings(g["seed"], g["b"], g["d"], g["clustered"])
+    img, txt = torch.tensor(img_np).to(DEV), torch.tensor(txt_np).to(DEV)
+    probe = [(i % g["b"], j % g["d"]) for i, j in g["probe_index"]]
+    R = 1e-4
+
+    def rel(a, b):
+        return abs(a - b) <= R * abs(b)
+
+    loss, di, dt, dtemp = ops.contrastive_fwd_bwd(img, txt, 0.1, need_dtemp=True)
+    assert rel(loss.item(), v["contrastive_T0.1"]), (loss.item(), v["contrastive_T0.1"])
+    assert abs(di.double().norm().item() - v["contrastive_T0.1.g0.norm"]) <= 1e-3 * v["contrastive_T0.1.g0.norm"]
+    assert abs(dt.double().norm().item() - v["contrastive_T0.1.g1.norm"]) <= 1e-3 * v["contrastive_T0.1.g1.norm"]
+    np.testing.assert_allclose([di[i, j].item() for i, j in probe], v["contrastive_T0.1.g0.probe"], rtol=5e-3, atol=1e-9)
+    assert abs(dtemp.item() - v["contrastive_learnableT.g2.value"]) <= 2e-3 * abs(v["contrastive_learnableT.g2.value"])
+    loss, dx = ops.lunif_fwd_bwd(img, 2.0)
+    assert rel(loss.item(), v["lunif_img"]), (loss.item(), v["lunif_img"])
+    assert abs(dx.double().norm().item() - v["lunif_img.g0.norm"]) <= 2e-3 * v["lunif_img.g0.norm"]
+    np.testing.assert_allclose([dx[i, j].item() for i, j in probe], v["lunif_img.g0.probe"], rtol=1e-2, atol=1e-9)
+    loss, dx, _ = ops.lalign_fwd_bwd(img, txt, 2.0)
+    assert rel(loss.item(), v["lalign"])
+    c, inv = ops.centroid_fwd(img, txt)
+    loss, _ = ops.lunif_fwd_bwd(c, 2.0, need_grad=False)
+    assert rel(loss.item(), v["lunif_centroids"]), (loss.item(), v["lunif_centroids"])
+    loss, _ = ops.sparsify_fwd_bwd(img, need_grad=False)
+    assert rel(loss.item(), v["sparsify_img"])
+    # closed-form fp64 gradient of the oracle, full tensor (not only probes), at sizes it finishes in seconds
+    if g["b"] <= 4096:
+        _, d64, _, _ = L.contrastive_grads(img_np, txt_np, 0.1)
+        assert_close(di, torch.tensor(d64), 2e-3, 1e-8, "contrastive d_img vs fp64")
+        _, dx64 = L.lunif_grads(img_np, 2.0)
+        _, dxg = ops.lunif_fwd_bwd(img, 2.0)
+        assert_close(dxg, torch.tensor(dx64), 5e-3, 1e-8, "lunif dx vs fp64")
+
+
+def test_loss_head_properties(ops):
+    """Size-independent properties: permutation invariance, symmetry, determinism, identical-pair edge cases."""
+    L = _oracle()
+    img_np, txt_np = L.philox_embeddings(5, 1000, 512)       # ragged: not a multiple of any tile
+    img, txt = torch.tensor(img_np).to(DEV), torch.tensor(txt_np).to(DEV)
+    l1, d1, _, _ = ops.contrastive_fwd_bwd(img, txt, 0.1)
+    l2, d2, _, _ = ops.contrastive_fwd_bwd(img, txt, 0.1)
+    assert l1.item() == l2.item() and torch.equal(d1, d2), "not bit-stable run to run"
+    lt, _, _, _ = ops.contrastive_fwd_bwd(txt, img, 0.1)
+    assert abs(lt.item() - l1.item()) <= 1e-6 * abs(l1.item()), "InfoNCE must be symmetric in its arguments"
+    perm = torch.randperm(1000, generator=torch.Generator().manual_seed(0)).to(DEV)
+    lu, _ = ops.lunif_fwd_bwd(img, 2.0)
+    lp, _ = ops.lunif_fwd_bwd(img[perm].contiguous(), 2.0)
+    assert abs(lu.item() - lp.item()) <= 2e-6 * abs(lu.item())
+    want = L.lunif_loss_gram(torch.tensor(img_np).double()).item()
+    assert abs(lu.item() - want) <= 1e-5 * abs(want)
+    # x == y: lalign is exactly 0 with a zero (sub-)gradient, as torch.norm's backward gives
+    la, dx, dy = ops.lalign_fwd_bwd(img, img.clone(), 2.0)
+    assert la.item() == 0.0 and not dx.any() and not dy.any()
+    la, dx, _ = ops.lalign_fwd_bwd(img, img.clone(), 1.0)
+    assert la.item() == 0.0 and torch.isfinite(dx).all() and not dx.any()
+    # smallest batch
+    l, d, _, _ = ops.contrastive_fwd_bwd(img[:2].contiguous(), txt[:2].contiguous(), 0.1)
+    want, d64, _, _ = L.contrastive_grads(img_np[:2], txt_np[:2], 0.1)
+    assert abs(l.item() - want) <= 1e-5 * abs(want)
+    assert_close(d, torch.tensor(d64), 1e-4, 1e-7, "B=2 grad")
+    from sparsify_clip_amd._lib import ScError
+    with pytest.raises(ScError):
+        ops.lunif_fwd_bwd(img[:1].contiguous(), 2.0)          # a single row has no pairs
+
+
+def test_l2norm_and_axpy(ops):
+    L = _oracle()
+    x = rnd(37, 512, seed=31)
+    y, inv = ops.l2norm_fwd(x.to(DEV), 0.0)
+    assert_close(y, L.normalize_rows(x.double()), 1e-6, 1e-7, "l2norm fwd")
+    dy = rnd(37, 512, seed=32)
+    dx = ops.l2norm_bwd(y, inv, dy.to(DEV))
+    assert_close(dx, torch.tensor(L.normalize_backward(x.numpy(), dy.numpy())), 1e-4, 1e-6, "l2norm bwd")
+    a = rnd(1000, seed=33).to(DEV)
+    b = rnd(1000, seed=34).to(DEV)
+    want = b.double().cpu() + 0.25 * a.double().cpu()
+    ops.axpy_(b, 0.25, a)
+    assert_close(b, want, 1e-6, 1e-6, "axpy")
+
+
+def test_retrieval_ranks(ops, golden_metrics):
+    from oracle import metrics as M
+    arr, v = golden_metrics
+    f1, f2 = torch.tensor(arr["f1"]), torch.tensor(arr["f2"])
+    score = f2 @ (0.6 * f2 + 0.4 * f1).t()
+    rf, rb, tf, tb = ops.retrieval_ranks(score.to(DEV))
+    assert rf.cpu().tolist() == M.retrieval_ranks(score, "forward").tolist()
+    assert rb.cpu().tolist() == M.retrieval_ranks(score, "backward").tolist()
+    assert tf.cpu().tolist() == v["top1_forward"]          # bit-exact top-1 indices (north_star)
+    assert tb.cpu().tolist() == v["top1_backward"]
+
+
+# ------------------------------------------------------------------------------------------------ encoder pieces
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,w", [(203, 512), (64, 768), (10, 1024)])
+def test_layernorm(ops, dtype, rows, w):
+    x, gam, bet = rnd(rows, w, seed=41, scale=2.0), 1 + 0.1 * rnd(w, seed=42), 0.1 * rnd(w, seed=43)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), dtype)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x64, (w,), g64, b64, 1e-5)
+    tol = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    assert_close(y, ref, *tol, "ln fwd")
+    dy = rnd(rows, w, seed=44).to(dtype)
+    dres = rnd(rows, w, seed=45)
+    ref.backward(dy.double())
+    dx, dx_cast, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gam.to(DEV), dres=dres.to(DEV), want_cast=True)
+    assert_close(dx, x64.grad + dres.double(), 1e-4, 1e-4, "ln dx")
+    assert_close(dx_cast, x64.grad + dres.double(), *tol if dtype == torch.bfloat16 else (1e-4, 1e-4), "ln dx cast")
+    assert_close(dg, g64.grad, 1e-4, 1e-3, "ln dgamma")
+    assert_close(db, b64.grad, 1e-4, 1e-3, "ln dbeta")
+
+
+def _ref_attention(qkv, batch, seq, heads, causal):
+    w = qkv.shape[1] // 3
+    q, k, v = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in qkv.split(w, dim=1)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((seq, seq), float("-inf"), dtype=s.dtype).triu_(1)
+    o = torch.softmax(s, dim=-1) @ v
+    return o.transpose(1, 2).reshape(batch * seq, w)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (128, 1, False)])
+def test_attention(ops, dtype, seq, heads, causal):
+    batch, w = 3, heads * 64
+    qkv = rnd(batch * seq, 3 * w, seed=51).to(dtype)
+    q64 = qkv.double().requires_grad_(True)
+    ref = _ref_attention(q64, batch, seq, heads, causal)
+    out = ops.attention_fwd(qkv.to(DEV), batch, seq, heads, causal)
+    tol = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    assert_close(out, ref, *tol, "attention fwd")
+    if seq <= 77:
+        d_out = rnd(batch * seq, w, seed=52).to(dtype)
+        ref.backward(d_out.double())
+        d_qkv = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal)
+        tolb = (1e-4, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+        assert_close(d_qkv, q64.grad, *tolb, "attention bwd")
+
+
+def test_colsum_cast_transpose(ops):
+    x = rnd(1000, 2304, seed=61)
+    assert_close(ops.colsum(x.to(DEV)), x.double().sum(0), 1e-5, 1e-3, "colsum f32")
+    xb = x.to(torch.bfloat16)
+    out = torch.ones(2304, device=DEV)
+    ops.colsum(xb.to(DEV), out=out, accumulate=True)
+    assert_close(out, xb.double().sum(0) + 1, 1e-5, 1e-3, "colsum bf16 accumulate")
+    src = rnd(70, 130, seed=62)
+    assert torch.equal(ops.cast_bf16(src.to(DEV)).cpu(), src.to(torch.bfloat16))
+    assert torch.equal(ops.transpose_cast_bf16(src.to(DEV)).cpu(), src.t().contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vit_stem(ops, dtype):
+    b, res, p, w = 3, 64, 32, 128
+    g = res // p
+    img = rnd(b, 3, res, res, seed=71)
+    cols = ops.im2col(img.to(DEV), p, 3 * p * p + 64, dtype)
+    ref = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(b * g * g, 3 * p * p)
+    assert torch.equal(cols[:, : 3 * p * p].float().cpu(), ref.to(dtype).float())
+    assert not cols[:, 3 * p * p:].any()
+    seq = g * g + 1
+    patch_out, cls, pos = rnd(b * g * g, w, seed=72).to(dtype), rnd(w, seed=73), rnd(seq, w, seed=74)
+    x = ops.vit_tokens_fwd(patch_out.to(DEV), cls.to(DEV), pos.to(DEV), b, seq)
+    want = torch.cat([cls.expand(b, 1, w), patch_out.float().reshape(b, g * g, w)], dim=1) + pos
+    assert_close(x, want.reshape(b * seq, w), 1e-6, 1e-6, "vit tokens fwd")
+    dx = rnd(b * seq, w, seed=75)
+    d_cls, d_pos = torch.ones(w, device=DEV), torch.ones(seq, w, device=DEV)
+    d_patch = ops.vit_tokens_bwd(dx.to(DEV), b, seq, dtype, d_cls, d_pos, True)
+    dx3 = dx.reshape(b, seq, w)
+    assert torch.equal(d_patch.float().cpu(), dx3[:, 1:].reshape(-1, w).to(dtype).float())
+    assert_close(d_cls, dx3[:, 0].double().sum(0) + 1, 1e-6, 1e-5, "d_cls")
+    assert_close(d_pos, dx3.double().sum(0) + 1, 1e-6, 1e-5, "d_pos")
+
+
+def test_text_stem_and_pool(ops):
+    b, s, w, vocab = 5, 16, 64, 300
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randint(1, vocab - 2, (b, s), generator=g)
+    tokens[:, 0] = vocab - 2
+    eot_pos = torch.tensor([5, 9, 3, 15, 7])
+    for i in range(b):
+        tokens[i, eot_pos[i]] = vocab - 1
+        tokens[i, eot_pos[i] + 1:] = 0
+    tokens[1, 1] = tokens[0, 1]  # a repeated word across captions
+    emb, pos = rnd(vocab, w, seed=81), rnd(s, w, seed=82)
+    x = ops.text_embed_fwd(tokens.to(DEV), emb.to(DEV), pos.to(DEV))
+    assert_close(x, (emb[tokens] + pos).reshape(b * s, w), 0, 0, "text embed fwd")
+    eot = ops.argmax_tokens(tokens.to(DEV))
+    assert eot.cpu().tolist() == eot_pos.tolist() == tokens.argmax(-1).tolist()
+    pooled = ops.pool_gather(x, eot, b, s)
+    assert torch.equal(pooled.cpu(), (emb[tokens] + pos)[torch.arange(b), eot_pos])
+    first = ops.pool_gather(x, None, b, s)
+    assert torch.equal(first.cpu(), (emb[tokens] + pos)[:, 0])
+    # backward: rows after EOT carry zero gradient and are left out of the sorted list
+    dx = rnd(b * s, w, seed=83).reshape(b, s, w)
+    active = torch.arange(s)[None, :] <= eot_pos[:, None]
+    dx = (dx * active[..., None]).reshape(b * s, w)
+    flat = tokens.reshape(-1)
+    idx = active.reshape(-1).nonzero().squeeze(1)
+    st, perm = torch.sort(flat[idx], stable=True)
+    order = idx[perm]
+    d_emb, d_pos = torch.zeros(vocab, w, device=DEV), torch.zeros(s, w, device=DEV)
+    ops.text_embed_bwd(dx.to(DEV), st.to(DEV), order.to(DEV), b, s, d_emb, d_pos, False)
+    want = torch.zeros(vocab, w, dtype=torch.float64).index_add_(0, flat, dx.double())
+    assert_close(d_emb, want, 1e-6, 1e-6, "token embedding scatter-add")
+    assert_close(d_pos, dx.reshape(b, s, w).double().sum(0), 1e-6, 1e-6, "text d_pos")
+    dxs = torch.zeros(b * s, w, device=DEV)
+    ops.pool_scatter(pooled, eot, b, s, dxs)
+    want = torch.zeros(b, s, w)
+    want[torch.arange(b), eot_pos] = pooled.cpu()
+    assert torch.equal(dxs.cpu(), want.reshape(b * s, w))
+
+
+def test_adamw_matches_torch(ops):
+    n = 5003
+    p0, g = rnd(n, seed=91), [rnd(n, seed=92 + i, scale=0.1) for i in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    p = p0.to(DEV).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step, gi in enumerate(g, 1):
+        ref.grad = gi.clone()
+        opt.step()
+        ops.adamw_step(p, gi.to(DEV), m, v, shadow, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    assert_close(p, ref.detach(), 1e-6, 1e-7, "adamw params")
+    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))

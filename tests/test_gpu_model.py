@@ -1,0 +1,174 @@
+"""GPU parity tests, model level: the HIP towers and the whole training step against the oracle's plain-torch CPU
+restatement on identical weights and inputs (fp32 path: the 1e-4 bar of north_star; bf16 path: bounded separately).
+The encoder oracle itself is "parity unpinned" by the reference (open_clip absent) - see oracle/clip_model.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sparsify_clip_amd.model as M
+    return M
+
+
+def rel_err(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).norm() / want.norm().clamp_min(1e-30)).item()
+
+
+def _pair(pkg, name, precision, seed=3):
+    from oracle.clip_model import create_model
+    ref = create_model(name, seed=seed)
+    model = pkg.ClipModel(name, device=DEV, precision=precision, seed=0)
+    model.load_state_dict(ref.state_dict())
+    return ref, model
+
+
+@pytest.mark.parametrize("name", ["tiny", "test-small"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_towers_forward_backward(pkg, name, precision):
+    from oracle.clip_model import synthetic_batch
+    ref, model = _pair(pkg, name, precision)
+    batch = 6
+    images_np, tokens_np = synthetic_batch(11, batch, ref.cfg)
+    images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+    ei, et = ref.encode_image(images), ref.encode_text(tokens)
+    g = torch.Generator().manual_seed(5)
+    di, dt = torch.randn(ei.shape, generator=g), torch.randn(et.shape, generator=g)
+    (ei * di).sum().backward()
+    (et * dt).sum().backward()
+    gi = model.image_forward(images.to(DEV))
+    gt = model.text_forward(tokens.to(DEV))
+    tol = 2e-5 if precision == "fp32" else 3e-2
+    assert rel_err(gi, ei) < tol, ("image embeddings", rel_err(gi, ei))
+    assert rel_err(gt, et) < tol, ("text embeddings", rel_err(gt, et))
+    model.zero_grad()
+    model.image_backward(di.to(DEV))
+    model.text_backward(dt.to(DEV))
+    gtol = 2e-4 if precision == "fp32" else 6e-2
+    worst = []
+    for pname, p in ref.named_parameters():
+        if pname == "logit_scale":
+            assert p.grad is None
+            continue
+        e = rel_err(model.grad(pname), p.grad)
+        worst.append((e, pname))
+        if p.grad.norm() > 1e-12:
+            assert e < gtol, (pname, e, float(p.grad.norm()))
+    print("worst grads", sorted(worst, reverse=True)[:3])
+    # second backward without zero_grad accumulates
+    model.image_backward(di.to(DEV))
+    model.text_backward(dt.to(DEV))
+    p = "visual.transformer.resblocks.0.mlp.c_fc.weight"
+    assert rel_err(model.grad(p), 2 * dict(ref.named_parameters())[p].grad) < gtol
+
+
+def test_autograd_surface_matches_manual(pkg):
+    """encode_image/encode_text + the reference-signature loss functions through torch autograd."""
+    from oracle.clip_model import synthetic_batch
+    from oracle import loss_head as L
+    from sparsify_clip_amd import losses
+    ref, model = _pair(pkg, "tiny", "fp32")
+    images_np, tokens_np = synthetic_batch(12, 8, ref.cfg)
+    images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+    ri = L.normalize_rows(ref.encode_image(images))
+    rt = L.normalize_rows(ref.encode_text(tokens))
+    rloss = L.contrastive_loss(ri, rt, 0.1) + L.lalign_loss(ri, rt) + L.lunif_centroids(ri, rt)
+    rloss.backward()
+    ie = model.encode_image(images.to(DEV))
+    te = model.encode_text(tokens.to(DEV))
+    ie = ie / ie.norm(dim=-1, keepdim=True)
+    te = te / te.norm(dim=-1, keepdim=True)
+    loss = losses.contrastive_loss(ie, te, temperature=0.1) + losses.lalign_loss(ie, te) + losses.lunif_loss(losses.normalized_centroids(ie, te))
+    assert abs(loss.item() - rloss.item()) <= 1e-4 * abs(rloss.item())
+    model.zero_grad()
+    loss.backward()
+    for pname in ["visual.proj", "text_projection", "visual.conv1.weight", "token_embedding.weight", "transformer.resblocks.0.attn.in_proj_weight"]:
+        assert rel_err(model.grad(pname), dict(ref.named_parameters())[pname].grad) < 5e-4, pname
+
+
+def _config(loss_type, **kw):
+    cfg = {"project_name": "t", "run_name": "t", "seed": 42, "learning_rate": 1e-3, "batch_size": 8, "model": "tiny", "num_train_samples": 64,
+           "num_test_samples": 16, "epochs": 2, "loss_type": loss_type, "only_lunif_epochs": 0, "anchor_temperature": 0.1,
+           "anchor_temperature_learnable": False, "save_checkpoint_every_n_epochs": 20, "resume_checkpoint": False, "fp16": False,
+           "beta_warmup_epoch": 20, "beta_decay_epoch": 50, "alpha_warmup_epoch": 50, "alpha_increment_epoch": 50}
+    cfg.update(kw)
+    from sparsify_clip_amd.config import finalize_config
+    return finalize_config(cfg, 0, {"precision": "fp32"})
+
+
+@pytest.mark.parametrize("loss_type,kw", [
+    ("anchor", {"anchor_temperature_learnable": True}),
+    ("only_lunif_n_then_anchor+lalign+lunif(centroids)", {"only_lunif_epochs": 1}),
+    ("only_lunif_n_then_anchor+ALPHA*lalign+BETA*(lunif(text)+lunif(img))", {}),
+    ("only_lunif_n_then_anchor+lalign+BETA*lunif(centroids)", {}),
+    ("ANCHOR(IMAGE,TEXT)+LUNIF(CENTROIDS)", {}),
+])
+def test_training_trajectory_fp32(pkg, loss_type, kw):
+    """Per-step loss within 1e-4 relative of the CPU fp32 path over a multi-step trajectory (north_star parity bar):
+    covers the lr=0 first step, AdamW with weight decay on everything, the phase switch and the beta/alpha schedules."""
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    from sparsify_clip_amd.train import Trainer
+    cfg = _config(loss_type, **kw)
+    steps_per_epoch = 3
+    ref_model = create_model("tiny", seed=9)
+    cpu = CpuTrainer(cfg, steps_per_epoch, model=ref_model)
+    model = pkg.ClipModel("tiny", device=DEV, precision="fp32")
+    model.load_state_dict(ref_model.state_dict())
+    gpu = Trainer(cfg, DEV, steps_per_epoch, model=model)
+    k = 0
+    for epoch in range(cfg["epochs"]):
+        cpu.epoch = gpu.epoch = epoch
+        for _ in range(steps_per_epoch):
+            images_np, tokens_np = synthetic_batch(100 + k, cfg["batch_size"], ref_model.cfg)
+            images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+            want = cpu.step(images, tokens).item()
+            got = gpu.step(images.to(DEV), tokens.to(DEV)).item()
+            assert abs(got - want) <= 1e-4 * abs(want), (k, got, want)
+            k += 1
+    for pname in ["visual.proj", "token_embedding.weight", "visual.transformer.resblocks.1.mlp.c_proj.bias"]:
+        assert rel_err(model.param(pname), dict(ref_model.named_parameters())[pname]) < 1e-4, pname
+    if cfg["anchor_temperature_learnable"]:
+        assert abs(float(gpu.temperature.detach()) - float(cpu.temperature.detach())) < 1e-6
+
+
+def test_bf16_step_close_to_fp32(pkg):
+    """bf16 towers: same step, loss within a documented looser bound of the fp32 CPU path."""
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    from sparsify_clip_amd.train import Trainer
+    cfg = _config("only_lunif_n_then_anchor+lalign+lunif(centroids)")
+    ref_model = create_model("test-small", seed=9)
+    cfg["model"] = "test-small"
+    cpu = CpuTrainer(cfg, 4, model=ref_model)
+    model = pkg.ClipModel("test-small", device=DEV, precision="bf16")
+    model.load_state_dict(ref_model.state_dict())
+    gpu = Trainer(cfg, DEV, 4, model=model)
+    for k in range(3):
+        images_np, tokens_np = synthetic_batch(200 + k, 8, ref_model.cfg)
+        want = cpu.step(torch.tensor(images_np), torch.tensor(tokens_np)).item()
+        got = gpu.step(torch.tensor(images_np).to(DEV), torch.tensor(tokens_np).to(DEV)).item()
+        assert abs(got - want) <= 2e-2 * abs(want), (k, got, want)
+
+
+def test_evaluate_and_state_dict(pkg):
+    from sparsify_clip_amd.data import SyntheticLoader
+    from sparsify_clip_amd.train import evaluate_model
+    model = pkg.ClipModel("tiny", device=DEV, precision="fp32")
+    loader = SyntheticLoader(32, 16, 5, DEV, 64, 16, 512, distinct=2)
+    log = evaluate_model(model, loader, DEV)
+    for key in ["forward_r1", "forward_r5", "forward_r10", "forward_ravg", "backward_r1", "backward_ravg", "gap", "mean_angular_value_image",
+                "mean_angular_value_text", "uniformity", "mean_cosine_similarity_true_pairs"]:
+        assert key in log and np.isfinite(log[key])
+    sd = model.state_dict(prefix="module.")
+    assert "module.visual.conv1.weight" in sd and "module.logit_scale" in sd
+    other = pkg.ClipModel("tiny", device=DEV, precision="bf16", seed=1)
+    other.load_state_dict(sd)
+    assert torch.equal(other.param("text_projection"), model.param("text_projection"))

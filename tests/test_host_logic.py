@@ -1,0 +1,179 @@
+"""CPU tests of the host side: schedules, dispatch table, config loader, tokenizer/data, the C-ABI binding
+(library loads and exports every symbol the header declares; no compute without a GPU), and loud failure of the
+product path when it is asked to run on the CPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_json
+
+
+def test_schedules_match_reference_tables():
+    from sparsify_clip_amd import schedules as S
+    sched = load_json("schedules.json")
+    for row in sched["beta"]:
+        assert [S.get_beta(s, row["total"], row["warmup"], row["ramp"]) for s in row["steps"]] == row["values"]
+    for row in sched["alpha"]:
+        assert [S.get_alpha(s, row["total"], row["warmup"], row["ramp"]) for s in row["steps"]] == row["values"]
+    for row in sched["lr"]:
+        lam = S.lr_lambda_factory(row["warmup_steps"], row["total"], config={"only_lunif_epochs": row["only_lunif_epochs"]})
+        assert [lam(s) for s in row["steps"]] == row["values"]
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sch = S.get_cosine_schedule_with_warmup(opt, 280, 1400, config={"only_lunif_epochs": 0})
+    assert sch.get_last_lr()[0] == 0.0   # first optimiser step runs at lr = 0
+
+
+def test_dispatch_table_covers_every_reference_yaml():
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.loss_dispatch import LOSS_TABLE, validate_loss_type
+    from sparsify_clip_amd._lib import ScError
+    from oracle.dispatch import TABLE
+    cfgs = load_json("configs.json")
+    assert len(cfgs) == 14 and sum(v is None for v in cfgs.values()) == 1     # 13 runnable YAMLs + the empty all_experiments.yaml
+    seen = set()
+    for rel, raw in cfgs.items():
+        if raw is None:
+            continue
+        cfg = finalize_config(raw, 3)
+        assert cfg["device_id"] == 3 and isinstance(cfg["learning_rate"], float) and cfg["learning_rate"] == 1e-4
+        assert cfg["precision"] == "bf16" and cfg["model"] == "RN50" and cfg["batch_size"] == 256
+        seen.add(cfg["loss_type"])
+    assert seen == set(LOSS_TABLE) and len(seen) == 9
+    for name, warm, unif, use_beta, use_alpha, use_lalign in TABLE:      # package table == oracle table (pinned by dispatch.json)
+        spec = LOSS_TABLE[name]
+        assert (spec.warmup_phase, spec.unif, spec.use_beta, spec.use_alpha, spec.use_lalign) == (warm, unif, use_beta, use_alpha, use_lalign)
+    with pytest.raises(ScError):
+        validate_loss_type("anchor-roberta")
+
+
+def test_config_loader_files_dirs_overrides(tmp_path):
+    from sparsify_clip_amd.config import config_files, load_config
+    from sparsify_clip_amd._lib import ScError
+    import yaml
+    cfgs = load_json("configs.json")
+    key = [k for k in cfgs if "experiment_10" in k][0]
+    raw = dict(cfgs[key], learning_rate="1e-4")     # PyYAML parses 1e-4 as a string
+    d = tmp_path / "cfgs"
+    d.mkdir()
+    (d / "b.yaml").write_text(yaml.safe_dump(raw))
+    (d / "a_empty.yaml").write_text("# TODO\n")
+    (d / "notes.txt").write_text("x")
+    files = config_files(str(d))
+    assert [os.path.basename(f) for f in files] == ["a_empty.yaml", "b.yaml"]
+    assert load_config(files[0]) is None
+    cfg = load_config(files[1], 1, {"model": "ViT-B-32", "batch_size": 4096, "precision": None})
+    assert cfg["model"] == "ViT-B-32" and cfg["batch_size"] == 4096 and cfg["learning_rate"] == 1e-4 and cfg["alpha_warmup_epoch"] == 50
+    bad = dict(raw)
+    del bad["beta_decay_epoch"]
+    (d / "c.yaml").write_text(yaml.safe_dump(bad))
+    with pytest.raises(ScError):
+        load_config(str(d / "c.yaml"))
+    with pytest.raises(ScError):
+        config_files(str(tmp_path / "missing"))
+
+
+def test_cli_parses_reference_flags():
+    import sparsify_clip as cli
+    a = cli.parse_args(["--config", "x.yaml", "--device", "2"])
+    assert a.config == "x.yaml" and a.device == 2 and a.model is None and a.batch_size is None
+    with pytest.raises(SystemExit):
+        cli.parse_args(["--config", "x.yaml"])          # --device is required, as in the reference
+    for name in ["contrastive_loss", "lunif_loss", "lalign_loss", "sparsify_loss", "compute_centroids_only", "get_beta", "get_alpha",
+                 "get_cosine_schedule_with_warmup", "train_model", "evaluate_model", "main", "set_seed"]:
+        assert callable(getattr(cli, name))
+
+
+def test_tokenizer_and_synthetic_data():
+    from sparsify_clip_amd.data import EOT, SOT, HashTokenizer, SyntheticLoader, synthetic_batch
+    tok = HashTokenizer()
+    t = tok(["a dog on a bench", "A  DOG on a bench", " ".join(["w"] * 100)])
+    assert t.shape == (3, 77) and t.dtype == torch.long
+    assert torch.equal(t[0], t[1]) and t[0, 0] == SOT and t[0, 6] == EOT and not t[0, 7:].any()
+    assert t[2, 0] == SOT and t[2, 76] == EOT                       # truncation keeps EOT last
+    assert (t.argmax(-1) == torch.tensor([6, 6, 76])).all()
+    images, tokens = synthetic_batch(42, 5)
+    images2, tokens2 = synthetic_batch(42, 5)
+    assert torch.equal(images, images2) and torch.equal(tokens, tokens2) and images.shape == (5, 3, 224, 224)
+    eot_pos = tokens.argmax(-1)
+    assert ((eot_pos >= 6) & (eot_pos <= 31)).all() and (tokens[:, 0] == SOT).all()
+    loader = SyntheticLoader(40, 16, 1, "cpu", image_size=32, ctx=16, vocab=512)
+    assert len(loader) == 2 and len(list(loader)) == 2             # drop_last semantics
+
+
+def test_library_exports_every_declared_symbol():
+    from sparsify_clip_amd import _lib
+    header = open(os.path.join(ROOT, "include", "sparsify_hip.h")).read()
+    declared = set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sc_gemm_epilogue", "sc_block_desc"}
+    assert declared == set(_lib.LIB.protos), declared ^ set(_lib.LIB.protos)
+    dll = _lib.LIB.load()                      # raises if a declared symbol is not exported
+    assert dll.sc_abi_version() == 1
+    assert dll.sc_abi_sizeof(0) == ctypes.sizeof(_lib.BlockDesc)
+    assert dll.sc_abi_sizeof(1) == ctypes.sizeof(_lib.GemmEpilogue)
+    assert dll.sc_loss_workspace_bytes(8192, 512) > 8192 * 8192 * 4
+    # host-side argument validation works without a GPU and reports through sc_last_error
+    rc = dll.sc_gemm_bf16_nt(128, 128, 100, None, 100, None, 100, None, 128, 1, None, None)
+    assert rc < 0 and b"sc_gemm_bf16_nt" in dll.sc_last_error()
+    rc = dll.sc_lunif_fwd_bwd(None, 1, 512, 2.0, 1.0, None, None, None, 0, None)
+    assert rc < 0
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: CPU tensors or a CPU device raise instead of silently computing somewhere else."""
+    from sparsify_clip_amd import losses
+    from sparsify_clip_amd._lib import ScError
+    from sparsify_clip_amd.model import ClipModel
+    x = torch.randn(8, 16)
+    for fn in (lambda: losses.contrastive_loss(x, x, 0.1), lambda: losses.lunif_loss(x), lambda: losses.lalign_loss(x, x),
+               lambda: losses.sparsify_loss(x), lambda: losses.normalized_centroids(x, x)):
+        with pytest.raises(ScError):
+            fn()
+    with pytest.raises(ScError):
+        ClipModel("tiny", device="cpu")
+    with pytest.raises(ScError):
+        ClipModel("RN50", device="cuda:0")
+    import sparsify_clip_amd
+    src = "".join(open(os.path.join(ROOT, "sparsify_clip_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "sparsify_clip_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src       # the product never routes through the oracle
+
+
+def test_uniformity_signatures_on_cpu(golden_metrics):
+    import uniformity as U          # root-level alias, as `from uniformity import ...` in the reference
+    from sparsify_clip_amd import uniformity as PU
+    arr, v = golden_metrics
+    f1, f2 = torch.tensor(arr["f1"]), torch.tensor(arr["f2"])
+    assert abs(U.numpy_uniformity(f1, f2) - v["numpy_uniformity"]) < 1e-5 and isinstance(U.numpy_uniformity(f1, f2), float)
+    assert abs(U.torch_uniformity(f1, f2).item() - v["torch_uniformity"]) < 1e-5
+    assert abs(U.torch_uniformity1(f1).item() - v["torch_uniformity1"]) < 1e-5
+    assert abs(U.torch_uniformity_equivalent(f1).item() - v["torch_uniformity_equivalent"]) < 1e-5
+    assert abs(U.uniformity10(f1).item() - v["uniformity10"]) < 1e-4
+    assert abs(PU.uniformity(f1, f2) - v["sparsify_clip.uniformity"]) < 1e-5
+    assert abs(PU.compute_gap(f1, f2) - v["compute_gap"]) < 1e-6
+    assert abs(PU.compute_mean_angular_value_of_a_modality(f1) - v["mean_angular_value_f1"]) < 1e-6
+    assert abs(PU.mean_distance_of_true_pairs(f1, f2) - v["mean_distance_of_true_pairs"]) < 1e-6
+
+
+def test_model_layout_without_gpu():
+    """Parameter inventory of the native model == the oracle's open_clip-named state_dict (names, shapes, counts)."""
+    from oracle.clip_model import create_model
+    from sparsify_clip_amd import model as M
+    for name, total in [("ViT-B-32", 151_277_313), ("tiny", None)]:
+        ref = create_model(name)
+        stub = M.ClipModel.__new__(M.ClipModel)
+        stub.cfg = M.CONFIGS[name]
+        stub.grid = stub.cfg["image_size"] // stub.cfg["patch"]
+        stub.k_patch = 3 * stub.cfg["patch"] ** 2
+        stub._layout()
+        ref_shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        assert {k: tuple(s) for k, (o, s) in stub.slots.items()} == ref_shapes
+        if total:
+            assert sum(int(np.prod(s)) for s in ref_shapes.values()) == total
+        # buckets tile the trainable range without gaps or overlap, in backward order
+        spans = [s for _, s in stub.buckets]
+        assert spans[0][0] == 0 and spans[-1][1] == stub.n_trainable
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all(off % 64 == 0 for off, _ in stub.slots.values())
