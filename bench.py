@@ -23,6 +23,23 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as tdist  # noqa: E402
 
+T_START = time.perf_counter()
+
+
+def progress(msg):
+    """Stage marker on stderr (the JSON line on stdout stays the only stdout output)."""
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may actually use, capped at the GPU box's per-GPU share (16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+
+
 GF_PER_PAIR = {"ViT-B-32": 44.33, "ViT-L-14": 525.98}     # fwd+bwd = 3x fwd GFLOP per (image, caption) pair, SURVEY 8d
 PEAK_BF16_TFLOPS = 2500.0                                   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
@@ -89,14 +106,16 @@ def cpu_baseline(cfg, model_name, batch):
     """Oracle CPU step (plain torch fp32, the restatement pinned to the reference by tests/golden) on a bounded sample."""
     from oracle.clip_model import create_model, synthetic_batch
     from oracle.train_step import CpuTrainer
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     ref = create_model(model_name, seed=0)
     c = dict(cfg, batch_size=batch)
     tr = CpuTrainer(c, 100, model=ref)
     tr.epoch = 1
     images, tokens = synthetic_batch(1, batch, ref.cfg)
     images, tokens = torch.tensor(images), torch.tensor(tokens)
+    progress(f"cpu baseline: {torch.get_num_threads()} threads, warm-up step")
     tr.step(images, tokens)   # untimed first step (thread pool / allocator warm-up)
+    progress("cpu baseline: timed steps")
     n = 2
     t0 = time.perf_counter()
     for _ in range(n):
@@ -117,6 +136,7 @@ def main():
     from sparsify_clip_amd.train import Trainer
     global_batch = args.local_batch * world
     key, cfg = reference_config(args.experiment, args.model, global_batch, args.precision)
+    progress(f"rank {rank}/{world}: building {args.model} ({args.precision}) and synthetic batches")
     trainer = Trainer(cfg, device, steps_per_epoch=1000)
     trainer.epoch = max(1, cfg["only_lunif_epochs"])       # main phase: the full loss stack, not the warm-up branch
     c = trainer.model.cfg
@@ -129,6 +149,8 @@ def main():
 
     for i in range(args.warmup):
         trainer.step(*batches[i % 2])
+        torch.cuda.synchronize()
+        progress(f"warm-up step {i + 1}/{args.warmup} done")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -140,6 +162,7 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = t.item()
     last_loss = float(loss.item())
+    progress(f"timed {args.steps} steps in {elapsed:.3f}s")
     pairs_per_s = global_batch * args.steps / elapsed
     out = {"metric": "image-text pairs/sec", "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -151,6 +174,7 @@ def main():
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
     if rank == 0:
         if args.precision == "bf16":
+            progress("roofline: replaying the step's NT GEMM launches under HIP events")
             out["roofline"] = gemm_roofline(trainer.model, device)
         if args.cpu_baseline and world == 1:
             del trainer
