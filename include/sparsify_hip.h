@@ -122,17 +122,18 @@ int sc_retrieval_ranks(const float* score, int64_t n, int32_t* rank_fwd, int32_t
 /* LayerNorm(eps 1e-5, affine) over rows of a fp32 [rows,width] matrix -> y (dtype).  K3 */
 int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, const float* gamma, const float* beta,
                      void* y, int dtype, float* mean, float* rstd, void* stream);
-/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta accumulate (+=) when accumulate != 0. ws >= 2*256*width floats */
+/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta accumulate (+=) when accumulate != 0. ws >= 3*768*width floats */
 int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const float* mean, const float* rstd,
                      const float* gamma, int64_t rows, int64_t width, const float* dres, float* dx,
                      void* dx_cast /* optional copy of dx in `dtype`, the next GEMM's operand */,
-                     float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                     float* dgamma, float* dbeta, float* dx_colsum /* optional [width]: (+)= column sums of dx (a bias gradient) */,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* softmax(QK^T/sqrt(64) [+causal mask]) V for packed qkv [B*S, 3*W] (nn.MultiheadAttention in_proj layout). K5 */
 int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads,
                      int causal, void* stream);
 int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq,
                      int64_t width, int64_t heads, int causal, void* stream);
-/* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 256*n floats */
+/* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 768*n floats */
 int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate,
               void* ws, size_t ws_bytes, void* stream);
 /* K1: images fp32 [B,3,R,R] -> patches [B*g*g, kpad] (dtype), g = R/P, column (c,ky,kx); columns >= 3*P*P zero */
@@ -182,13 +183,15 @@ typedef struct sc_block_desc {
     /* backward: gradients of parameters, fp32, accumulated (+=) when accumulate != 0 */
     float *g_ln1_g, *g_ln1_b, *g_w_qkv, *g_b_qkv, *g_w_o, *g_b_o, *g_ln2_g, *g_ln2_b, *g_w_fc1, *g_b_fc1, *g_w_fc2, *g_b_fc2;
     int32_t accumulate;
-    int32_t _pad;
+    int32_t b_fc2_done;  /* != 0: g_b_fc2 was already produced by the block above (see g_below_b_fc2) */
     /* backward scratch (dtype unless noted): d_h [rows,mlp], d_ln [rows,W], d_qkv [rows,3W], d_attn [rows,W],
      * d_res_t [rows,W] (GEMM-operand copy of the fp32 residual gradients; unused for SC_F32) */
     void *d_h, *d_ln, *d_qkv, *d_attn, *d_res_t;
     float* dx_mid;      /* [rows,W] fp32 scratch */
     void* ws;           /* reduction workspace */
     size_t ws_bytes;
+    /* optional: the c_proj bias gradient of the block BELOW (= column sums of dx_in), fused into this block's ln_1 backward */
+    float* g_below_b_fc2;
 } sc_block_desc;
 
 size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype);

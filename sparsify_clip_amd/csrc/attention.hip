@@ -5,8 +5,19 @@
 // storage dtypes, so the same kernel serves the fp32 parity path and the bf16 path.
 // The text tower uses the additive causal mask of open_clip (-inf above the diagonal).
 #include "common.h"
+#include <stdlib.h>
+
+int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
+int sc_attention_mfma_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                          hipStream_t st);
 
 namespace {
+
+// SC_ATTENTION=valu forces the fp32-VALU kernels for bf16 too (A/B runs)
+bool use_mfma() {
+    static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return !(e && e[0] == 'v'); }();
+    return on;
+}
 
 constexpr int HD = 64;        // head dim
 constexpr int HDP = HD + 4;   // padded LDS row (floats): 272-B stride -> conflict-free ds_read_b128 across rows
@@ -164,6 +175,10 @@ extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t b
                                 void* stream) {
     SC_TRY(check("sc_attention_fwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && out, SC_ERR_ARG, "sc_attention_fwd: null argument");
+    if (dtype == SC_BF16 && use_mfma()) {
+        const int rc = sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     const size_t lds = ((size_t)3 * seq * HDP + 4 * 128) * sizeof(float);
     const float scale = 0.125f;  // 1/sqrt(64)
     const dim3 grid((unsigned)(batch * heads));
@@ -184,6 +199,10 @@ extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv,
                                 int64_t heads, int causal, void* stream) {
     SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
+    if (dtype == SC_BF16 && use_mfma()) {
+        const int rc = sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     const size_t lds = ((size_t)4 * seq * HDP + 2 * seq * (seq + 1)) * sizeof(float);
     SC_REQUIRE(lds <= 160 * 1024, SC_ERR_SHAPE, "sc_attention_bwd: sequence length %lld needs %zu bytes of LDS (> 160 KiB)", (long long)seq, lds);
     const float scale = 0.125f;

@@ -1,0 +1,375 @@
+// bf16 MFMA attention for the short sequences of the CLIP towers (S = 50 image tokens, S = 77 text tokens, head dim 64).
+// One WAVE owns one (batch, head); 4 heads per workgroup, no workgroup barriers.  Scores, probabilities and their
+// gradients never leave registers:
+//   * S'[j][i] = K Q^T is computed with the operands swapped, so a lane holds ONE query row i and the keys j sit in the
+//     accumulator registers: the softmax row reduction is in-register plus two cross-group shuffles;
+//   * the accumulator tile is fed straight back as the B operand of the next MFMA (P V, dS K): that product sums over
+//     the tile's ROW index, so no lane movement is needed - only the k order inside a 32-step is permuted
+//     (key j = 32s + 4g + e for e < 4, 32s + 16 + 4g + (e-4) for e >= 4), and the other operand is fetched with the same
+//     permutation by two ds_read_b64_tr_b16 of the row-major LDS image (cdna_hip_programming.md section 3 / T10);
+//   * products that sum over the QUERY index (dV = P^T dO, dK = dS^T Q) use the non-swapped tile S[i][j] (lane = key),
+//     recomputed in a second pass with the row statistics (m, 1/l, delta) handed over through a few LDS floats.
+// LDS images are row-major [rows][64] bf16 with a 144-byte row stride: ds_read_b128 row reads are conflict-free and the
+// transposed reads at most 2-way.  Padded rows are zero-filled, padded keys masked to probability 0.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int LDR = 72;   // LDS row stride in bf16 elements (144 B)
+
+typedef __attribute__((address_space(3))) bf16x4* ltr_t;
+
+__device__ __forceinline__ bf16x4 tr_read(const bf16_t* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)p); }
+
+// fragment of the transposed image for k-step s: element e <-> row 32s + 4g + e (e<4) / 32s + 16 + 4g + (e-4)
+template <bool HI_VALID>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int s, int col16, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const bf16_t* a = img + (32 * s + 4 * g + q) * LDR + col16 + 4 * p;
+    const bf16x4 lo = tr_read(a);
+    bf16x4 hi = {0, 0, 0, 0};
+    if (HI_VALID) hi = tr_read(a + 16 * LDR);
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+}
+
+// row fragment (A or B operand with the row on the lane): rows tile*16 + (lane&15), k = 32*ks + 8*(lane>>4) + e
+__device__ __forceinline__ bf16x8 row_frag_lds(const bf16_t* img, int tile, int ks, int lane) {
+    return *(const bf16x8*)(img + (tile * 16 + (lane & 15)) * LDR + 32 * ks + 8 * (lane >> 4));
+}
+__device__ __forceinline__ bf16x8 row_frag_global(const bf16_t* base, int64_t ld, int tile, int ks, int lane, int S) {
+    const int r = min(tile * 16 + (lane & 15), S - 1);
+    return *(const bf16x8*)(base + (int64_t)r * ld + 32 * ks + 8 * (lane >> 4));
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = (short)f32_to_bf16(lo[e]); f[4 + e] = (short)f32_to_bf16(hi[e]); }
+    return f;
+}
+
+// copy a [S][64] bf16 head slice (row stride ld) into an LDS image of NT*16 rows; rows >= S are zero
+template <int NT>
+__device__ __forceinline__ void stage_head(bf16_t* img, const bf16_t* src, int64_t ld, int S, int lane) {
+#pragma unroll
+    for (int it = 0; it < NT * 2; ++it) {
+        const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r < S) v = *(const uint4*)(src + (int64_t)r * ld + c);
+        *(uint4*)(img + r * LDR + c) = v;
+    }
+}
+
+__device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups that share one query row
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total_heads, float scale) {
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_fwd[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = blockIdx.x * 4 + wave;
+    if (head >= total_heads) return;
+    bf16_t* Vs = lds_fwd + wave * (NT * 16 * LDR);
+    const int b = head / H, h = head % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    const bf16_t* kb = qb + W;
+    stage_head<NT>(Vs, qb + 2 * W, ld, S, lane);
+    const int g = lane >> 4, c16 = lane & 15;
+
+    bf16x8 Kf[NT][2];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) Kf[jt][ks] = row_frag_global(kb, ld, jt, ks, lane, S);
+    bf16x8 Vf[4][KS];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            Vf[dt][s] = (ODD && s == KS - 1) ? tr_frag<false>(Vs, s, 16 * dt, lane) : tr_frag<true>(Vs, s, 16 * dt, lane);
+
+    const int n_it = (S + 15) >> 4;
+    for (int it = 0; it < n_it; ++it) {
+        const bf16x8 q0 = row_frag_global(qb, ld, it, 0, lane, S), q1 = row_frag_global(qb, ld, it, 1, lane, S);
+        const int i = it * 16 + c16;
+        f32x4 sc[NT + 1];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = MFMA16(Kf[jt][0], q0, a);
+            a = MFMA16(Kf[jt][1], q1, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const bool ok = j < S && (!CAUSAL || j <= i);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+                m = fmaxf(m, a[r]);
+            }
+            sc[jt] = a;
+        }
+        sc[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m = group_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[jt][r] - m);   // exp(-inf) = 0 for masked keys
+                sc[jt][r] = p;
+                l += p;
+            }
+        l = group_sum(l);
+        const float inv = 1.0f / l;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 pf = pack_frag(sc[2 * s], sc[2 * s + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = MFMA16(Vf[dt][s], pf, o[dt]);
+        }
+        if (i < S) {
+            bf16_t* op = out + ((int64_t)b * S + i) * W + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(op + 16 * dt, o[dt] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
+                                                            float scale) {
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    constexpr int IMG = NT * 16 * LDR;                 // elements per LDS image
+    constexpr int WAVE_ELEMS = 3 * IMG + 3 * NT * 16 * 2;   // 3 images + 3 fp32 stat rows (2 bf16 slots per float)
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_bwd[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = blockIdx.x * 4 + wave;
+    if (head >= total_heads) return;
+    bf16_t* Ks = lds_bwd + wave * WAVE_ELEMS;
+    bf16_t* Qs = Ks + IMG;
+    bf16_t* Os = Qs + IMG;                              // dO
+    float* st_m = (float*)(Os + IMG);                   // [NT*16] row max
+    float* st_il = st_m + NT * 16;                      // 1 / row sum
+    float* st_dl = st_il + NT * 16;                     // delta_i = sum_j p_ij dp_ij
+    const int b = head / H, h = head % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    const bf16_t* vb = qb + 2 * W;
+    const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
+    bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
+    stage_head<NT>(Qs, qb, ld, S, lane);
+    stage_head<NT>(Ks, qb + W, ld, S, lane);
+    stage_head<NT>(Os, dob, W, S, lane);
+    const int g = lane >> 4, c16 = lane & 15;
+
+    bf16x8 Vf[NT][2];     // V row fragments (rows = keys), used as A in pass 1 and as B in pass 2
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) Vf[jt][ks] = row_frag_global(vb, ld, jt, ks, lane, S);
+
+    const int n_t = (S + 15) >> 4;
+    // ---------------- pass 1: lane = query row i.  P, dS in registers -> dQ ; row statistics -> LDS
+    for (int it = 0; it < n_t; ++it) {
+        const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
+        const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
+        const int i = it * 16 + c16;
+        f32x4 sc[NT + 1], dp[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+            a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
+            a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+            d = MFMA16(Vf[jt][0], g0, d);
+            d = MFMA16(Vf[jt][1], g1, d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const bool ok = j < S && (!CAUSAL || j <= i);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+                m = fmaxf(m, a[r]);
+            }
+            sc[jt] = a;
+            dp[jt] = d;
+        }
+        sc[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m = group_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[jt][r] - m);
+                sc[jt][r] = p;
+                l += p;
+            }
+        l = group_sum(l);
+        const float inv = 1.0f / l;
+        float delta = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[jt][r] *= inv;
+                delta += sc[jt][r] * dp[jt][r];
+            }
+        delta = group_sum(delta);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[jt][r] = sc[jt][r] * (dp[jt][r] - delta) * scale;   // dS (0 where p = 0)
+        if (g == 0) {
+            const bool live = i < S;
+            st_m[i] = live ? m : 0.f;
+            st_il[i] = live ? inv : 0.f;
+            st_dl[i] = live ? delta : 0.f;
+        }
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 dsf = pack_frag(sc[2 * s], sc[2 * s + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kt = (ODD && s == KS - 1) ? tr_frag<false>(Ks, s, 16 * dt, lane) : tr_frag<true>(Ks, s, 16 * dt, lane);
+                dq[dt] = MFMA16(kt, dsf, dq[dt]);
+            }
+        }
+        if (i < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
+        }
+    }
+    // statistics rows of the padding tile (only read when NT is odd and the last k-step is half empty: never) stay untouched
+    // ---------------- pass 2: lane = key row j.  P^T, dS^T products -> dV, dK
+    for (int jt = 0; jt < n_t; ++jt) {
+        const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
+        const bf16x8 v0 = row_frag_global(vb, ld, jt, 0, lane, S), v1 = row_frag_global(vb, ld, jt, 1, lane, S);   // runtime jt: not Vf[jt] (scratch)
+        const int j = jt * 16 + c16;
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int it = 2 * s + u;
+                if (ODD && it >= NT) continue;   // compile-time: the empty half of the last k-step
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
+                a = MFMA16(row_frag_lds(Qs, it, 1, lane), k1, a);
+                d = MFMA16(row_frag_lds(Os, it, 0, lane), v0, d);
+                d = MFMA16(row_frag_lds(Os, it, 1, lane), v1, d);
+                const f32x4 mm = *(const f32x4*)(st_m + it * 16 + 4 * g), il = *(const f32x4*)(st_il + it * 16 + 4 * g),
+                            dl = *(const f32x4*)(st_dl + it * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + 4 * g + r;
+                    const bool ok = i < S && j < S && (!CAUSAL || j <= i);
+                    const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
+                    pt[u][r] = p;
+                    dst[u][r] = p * (d[r] - dl[r]) * scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(pt[0], pt[1]), dsf = pack_frag(dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 ot = (ODD && s == KS - 1) ? tr_frag<false>(Os, s, 16 * dt, lane) : tr_frag<true>(Os, s, 16 * dt, lane);
+                const bf16x8 qt = (ODD && s == KS - 1) ? tr_frag<false>(Qs, s, 16 * dt, lane) : tr_frag<true>(Qs, s, 16 * dt, lane);
+                dv[dt] = MFMA16(ot, pf, dv[dt]);
+                dk[dt] = MFMA16(qt, dsf, dk[dt]);
+            }
+        }
+        if (j < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + W + 16 * dt + 4 * g, dk[dt]);
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + 2 * W + 16 * dt + 4 * g, dv[dt]);
+            }
+        }
+    }
+}
+
+template <typename K>
+int reserve_lds(K kernel, size_t bytes) {
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return sc_set_error((int)e, "attention(mfma): cannot reserve %zu bytes of LDS: %s", bytes, hipGetErrorString(e));
+    }
+    return SC_OK;
+}
+
+template <int NT>
+int launch_fwd(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total, bool causal, hipStream_t st) {
+    const size_t lds = (size_t)4 * NT * 16 * LDR * sizeof(bf16_t);
+    const dim3 grid((unsigned)sc_cdiv(total, 4));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_fwd_mfma_kernel<NT, true>, lds));
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, true>), grid, dim3(256), lds, st, qkv, out, S, W, H, total, 0.125f);
+    } else {
+        SC_TRY(reserve_lds(attn_fwd_mfma_kernel<NT, false>, lds));
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, false>), grid, dim3(256), lds, st, qkv, out, S, W, H, total, 0.125f);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+template <int NT>
+int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, hipStream_t st) {
+    const size_t lds = (size_t)4 * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
+    const dim3 grid((unsigned)sc_cdiv(total, 4));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true>, lds));
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f);
+    } else {
+        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false>, lds));
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+}  // namespace
+
+// bf16, seq <= 80: MFMA path.  Returns SC_OK after launching, or 1 when the shape is not covered (caller falls back to the
+// whole-head-in-LDS fp32-VALU kernel, which is also the fp32 parity path).
+int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+    if (seq > 80) return 1;
+    const int total = (int)(batch * heads);
+    if (seq <= 64) return launch_fwd<4>((const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, total, causal != 0, st);
+    return launch_fwd<5>((const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, total, causal != 0, st);
+}
+int sc_attention_mfma_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                          hipStream_t st) {
+    if (seq > 80) return 1;
+    const int total = (int)(batch * heads);
+    if (seq <= 64) return launch_bwd<4>((const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width, (int)heads, total, causal != 0, st);
+    return launch_bwd<5>((const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width, (int)heads, total, causal != 0, st);
+}

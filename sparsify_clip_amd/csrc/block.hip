@@ -55,9 +55,9 @@ int check_desc(const sc_block_desc* d, const char* who) {
 
 extern "C" size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype) {
     if (rows <= 0 || width <= 0 || mlp_width <= 0) return 0;
-    size_t need = (size_t)256 * 2 * (size_t)width * sizeof(float);                       // LayerNorm partials
+    size_t need = (size_t)768 * 3 * (size_t)width * sizeof(float);                       // LayerNorm partials
     const size_t widest = (size_t)(mlp_width > 3 * width ? mlp_width : 3 * width);
-    need = need > 256 * widest * sizeof(float) ? need : 256 * widest * sizeof(float);   // column-sum partials
+    need = need > 768 * widest * sizeof(float) ? need : 768 * widest * sizeof(float);   // column-sum partials
     if (dtype == SC_BF16) {
         const int64_t shapes[4][2] = {{3 * width, width}, {width, width}, {mlp_width, width}, {width, mlp_width}};
         for (auto& s : shapes) {
@@ -120,7 +120,7 @@ extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const v
     }
     // ---- MLP half: c_proj, GELU', c_fc
     SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, d->ws, d->ws_bytes, st));
-    SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));
+    if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));
     EpiParams e = epi_plain();
     e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
@@ -129,11 +129,10 @@ extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const v
     SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
     // dx_mid = dx_out + LN2'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_mid, d->ln2_mean, d->ln2_rstd, d->ln2_g, rows, W, dx_out, d->dx_mid, bf ? d->d_res_t : nullptr,
-                            d->g_ln2_g, d->g_ln2_b, acc, d->ws, d->ws_bytes, stream));
+                            d->g_ln2_g, d->g_ln2_b, d->g_b_o /* out_proj bias gradient = column sums of dx_mid */, acc, d->ws, d->ws_bytes, stream));
     const void* gm = bf ? (const void*)d->d_res_t : (const void*)d->dx_mid;
     // ---- attention half: out_proj, attention, in_proj
     SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, d->ws, d->ws_bytes, st));
-    SC_TRY(sc_colsum(d->dx_mid, SC_F32, rows, W, W, d->g_b_o, acc, d->ws, d->ws_bytes, stream));
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
     SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, d->ws, d->ws_bytes, st));
@@ -141,6 +140,6 @@ extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const v
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
     // dx_in = dx_mid + LN1'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,
-                            d->g_ln1_b, acc, d->ws, d->ws_bytes, stream));
+                            d->g_ln1_b, d->g_below_b_fc2, acc, d->ws, d->ws_bytes, stream));
     return SC_OK;
 }

@@ -91,4 +91,25 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// bf16 epilogues: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16 resolution) - one v_exp + one v_rcp
+// instead of erff's long polynomial; exp(-x^2/2) is shared between the cdf and the pdf of the GELU derivative.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float e = __expf(-z * z);                                   // exp(-x^2/2)
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float tail = 0.5f * poly * e;                               // 0.5 * erfc(|x|/sqrt 2): no cancellation in the tails
+    cdf = x >= 0.f ? 1.0f - tail : tail;
+    pdf_x = x * 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float cdf, pdfx;
+    gelu_parts_fast(x, cdf, pdfx);
+    return x * cdf;
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float cdf, pdfx;
+    gelu_parts_fast(x, cdf, pdfx);
+    return cdf + pdfx;
+}
 #endif

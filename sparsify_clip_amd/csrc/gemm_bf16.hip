@@ -15,6 +15,7 @@
 // Workgroup ids are remapped so that each XCD walks a contiguous range of tiles (A-panel reuse in its own L2).
 #include "common.h"
 #include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -91,23 +92,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Params p) 
     const int frow = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* abase = smem + cur * BUF_BYTES + (wm * 64 + frow) * 128;
         const char* bbase = smem + cur * BUF_BYTES + OPER_BYTES + (wn * 64 + frow) * 128;
+        // all fragments of this K-tile into registers first: the LDS-DMA of the next tile is then issued with no LDS read
+        // behind it, so hipcc places no vmcnt(0) in front of the MFMAs and the loads fly under the 32 MFMAs
+        bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int pos = ((4 * s + fq) ^ (lane & 7)) * 16;
-            bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(abase + i * 16 * 128 + pos);
+            for (int i = 0; i < 4; ++i) af[s][i] = *(const bf16x8*)(abase + i * 16 * 128 + pos);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(bbase + j * 16 * 128 + pos);
+            for (int j = 0; j < 4; ++j) bfr[s][j] = *(const bf16x8*)(bbase + j * 16 * 128 + pos);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -127,6 +135,126 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Params p) 
             } else {
                 bf16_t* cp = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
                 io<bf16_t>::st4(cp, epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, nullptr));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NT, 256x128, 3-stage
+// 8 waves as 4(M) x 2(N), each wave a 64x64 sub-tile (4x4 MFMA tiles).  Three LDS stages of (32 KiB A + 16 KiB B):
+// the LDS-DMA of K-tile t+2 is issued right after the barrier that publishes tile t, and only a COUNTED vmcnt
+// (the youngest stage, 6 DMA per wave, stays in flight) is waited for - HBM/L2 latency hides under two tiles of MFMAs.
+// The K loop is unrolled by the stage count so every LDS offset is a compile-time constant.
+// Tiles are walked in groups of GROUP_N column tiles inside each XCD's chunk so that the ~32 workgroups an XCD runs
+// at once share 8 A panels and 4 B panels (fits its 4 MiB L2).
+constexpr int T_M = 256, T_N = 128, STAGES = 3, GROUP_N = 4;
+constexpr int STAGE_BYTES = (T_M + T_N) * 128;   // 49152
+constexpr int A_BYTES = T_M * 128;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD chunk -> grouped (GROUP_N column tiles wide, row-major inside the group) tile order
+    int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int per_group = p.tiles_m * GROUP_N;
+    const int grp = tile / per_group, rem = tile - grp * per_group;
+    const int gw = min(GROUP_N, p.tiles_n - grp * GROUP_N);
+    const int m0 = (rem / gw) * T_M, n0 = (grp * GROUP_N + rem % gw) * T_N;
+
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const bf16_t* ga[4];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ga[q] = p.A + (int64_t)min(m0 + wave * 32 + q * 8 + srow, p.M - 1) * p.lda + schunk * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) gb[q] = p.B + (int64_t)min(n0 + wave * 16 + q * 8 + srow, p.N - 1) * p.ldb + schunk * 8;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / KSTEP;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int pos0 = ((fq) ^ (lane & 7)) * 16, pos1 = ((4 + fq) ^ (lane & 7)) * 16;
+
+#define NT256_STAGE(S, KT)                                                                            \
+    do {                                                                                              \
+        char* ab__ = smem + (S) * STAGE_BYTES + (wave * 32) * 128;                                    \
+        char* bb__ = smem + (S) * STAGE_BYTES + A_BYTES + (wave * 16) * 128;                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(ga[q] + (KT) * KSTEP, ab__ + q * 8 * 128); \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) glds16(gb[q] + (KT) * KSTEP, bb__ + q * 8 * 128); \
+    } while (0)
+
+#define NT256_BODY(S, KT)                                                                             \
+    do {                                                                                              \
+        if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                           \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) NT256_STAGE(((S) + 2) % STAGES, (KT) + 2);                                 \
+        const char* ab__ = smem + (S) * STAGE_BYTES + (wm * 64 + frow) * 128;                         \
+        const char* bb__ = smem + (S) * STAGE_BYTES + A_BYTES + (wn * 64 + frow) * 128;               \
+        bf16x8 af__[2][4], bf__[2][4];                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            af__[0][i] = *(const bf16x8*)(ab__ + i * 16 * 128 + pos0);                                \
+            af__[1][i] = *(const bf16x8*)(ab__ + i * 16 * 128 + pos1);                                \
+            bf__[0][i] = *(const bf16x8*)(bb__ + i * 16 * 128 + pos0);                                \
+            bf__[1][i] = *(const bf16x8*)(bb__ + i * 16 * 128 + pos1);                                \
+        }                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf__[s][j], af__[s][i], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+    } while (0)
+
+    NT256_STAGE(0, 0);
+    if (nk > 1) NT256_STAGE(1, 1);
+    for (int kt = 0; kt < nk; kt += STAGES) {
+        NT256_BODY(0, kt);
+        if (kt + 1 < nk) NT256_BODY(1, kt + 1);
+        if (kt + 2 < nk) NT256_BODY(2, kt + 2);
+    }
+#undef NT256_BODY
+#undef NT256_STAGE
+
+    // Epilogue through LDS: each wave parks its 64x64 fp32 sub-tile in its own slab (row stride 68 floats), then walks
+    // it row-major so that every lane owns 8 consecutive columns of one row: bias / GELU / residual loads and the C
+    // store are 16-byte pieces, 8 lanes per 128-B row, instead of 8-byte pieces scattered over 16 rows.
+    __syncthreads();   // every wave is done reading the last K-tile
+    float* slab = (float*)smem + wave * (64 * 68);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (16 * i + frow) * 68 + 16 * j + 4 * fq) = acc[i][j];
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + ecol;
+    if (n < p.N) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + erow;
+            const int m = m0 + wm * 64 + row;
+            if (m >= p.M) continue;
+            const f32x4 v0 = *(const f32x4*)(slab + row * 68 + ecol), v1 = *(const f32x4*)(slab + row * 68 + ecol + 4);
+            if (OUT_F32) {
+                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                const f32x4 r0 = epi_vec4<bf16_t>(p.epi, v0, m, n, cp), r1 = epi_vec4<bf16_t>(p.epi, v1, m, n + 4, cp + 4);
+                *(f32x4*)cp = r0;
+                *(f32x4*)(cp + 4) = r1;
+            } else {
+                const f32x4 r0 = epi_vec4<bf16_t>(p.epi, v0, m, n, nullptr), r1 = epi_vec4<bf16_t>(p.epi, v1, m, n + 4, nullptr);
+                uint4 u;
+                u.x = (unsigned)f32_to_bf16(r0[0]) | ((unsigned)f32_to_bf16(r0[1]) << 16);
+                u.y = (unsigned)f32_to_bf16(r0[2]) | ((unsigned)f32_to_bf16(r0[3]) << 16);
+                u.z = (unsigned)f32_to_bf16(r1[0]) | ((unsigned)f32_to_bf16(r1[1]) << 16);
+                u.w = (unsigned)f32_to_bf16(r1[2]) | ((unsigned)f32_to_bf16(r1[3]) << 16);
+                *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
             }
         }
     }
@@ -199,12 +327,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
     const int swz = (q4 | ((g & 1) << 2)) << 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
         const char* abase = smem + cur * BUF_BYTES;
         const char* bbase = abase + OPER_BYTES;
+        bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = 32 * s + 8 * g + 4 * h + q4;
@@ -216,17 +343,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
                     const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(bbase + row * 256 + ((cb ^ swz) << 4) + ((pp & 1) << 3)));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        af[i][4 * h + e] = va[e];
-                        bfr[i][4 * h + e] = vb[e];
+                        af[s][i][4 * h + e] = va[e];
+                        bfr[s][i][4 * h + e] = vb[e];
                     }
                 }
             }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < kt_end) zero_tail(cur ^ 1, kt + 1);
@@ -292,12 +425,20 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)k;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
     p.splits = 1; p.k_per_split = 0; p.partial = nullptr;
     p.epi = epi;
-    const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
-    if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    static const bool small_tile = [] { const char* e = getenv("SC_GEMM_NT"); return e && e[0] == '1'; }();   // SC_GEMM_NT=128: A/B runs
+    if (small_tile || n % 8 != 0 || ldc % 8 != 0 || (epi.ld_aux % 8 != 0 && (epi.pre_out || epi.resid || epi.dgelu_pre))) {
+        p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
+        const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+        if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    } else {
+        p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
+        const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+        if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
+    }
     SC_CHECK_LAUNCH();
     return SC_OK;
 }

@@ -60,14 +60,15 @@ __device__ __forceinline__ f32x4 epi_vec4(const EpiParams& e, f32x4 acc, int m, 
     if (e.bias) v += *(const f32x4*)(e.bias + n);
     const int64_t off = (int64_t)m * e.ld_aux + n;
     if (e.pre_out) io<TAux>::st4((TAux*)e.pre_out + off, v);
+    constexpr bool FAST = sizeof(TAux) == 2;   // bf16 activations: the 1.5e-7 erf approximation is exact at bf16 resolution
     if (e.act == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = FAST ? gelu_fast(v[j]) : gelu_f(v[j]);
     }
     if (e.dgelu_pre) {
         const f32x4 h = io<TAux>::ld4((const TAux*)e.dgelu_pre + off);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(h[j]);
+        for (int j = 0; j < 4; ++j) v[j] *= FAST ? gelu_grad_fast(h[j]) : gelu_grad_f(h[j]);
     }
     if (e.resid) v += (e.resid_dtype == SC_F32) ? io<float>::ld4((const float*)e.resid + off) : io<bf16_t>::ld4((const bf16_t*)e.resid + off);
     if (e.beta != 0.f && c_old) v += *(const f32x4*)c_old * e.beta;

@@ -7,67 +7,77 @@
 namespace {
 
 constexpr int LN_MAX_CHUNKS = 8;     // width <= 2048
-constexpr int RED_MAX_BLOCKS = 256;  // partial slabs of the column reductions
+constexpr int RED_MAX_BLOCKS = 768;  // partial slabs of the column reductions (3 workgroups per CU)
 constexpr float LN_EPS = 1e-5f;
 
-template <typename T>
+// RPW rows per wave: all loads of the wave's rows are issued before the first reduction (memory-level parallelism)
+template <typename T, int RPW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int64_t rows, int width, const float* gamma, const float* beta,
                                                             T* y, float* mean_out, float* rstd_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + row * width;
-    f32x4 v[LN_MAX_CHUNKS];
-    float s = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    f32x4 v[RPW][LN_MAX_CHUNKS];
+    float s[RPW];
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
-        const int idx = c * 256 + lane * 4;
-        if (idx < width) {
-            v[c] = *(const f32x4*)(xr + idx);
-            s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
-        }
-    }
-    const float mean = wave_sum(s) / (float)width;
-    float q = 0.f;
+    for (int r = 0; r < RPW; ++r) {
+        s[r] = 0.f;
+        const int64_t row = min(row0 + r, rows - 1);
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
-        const int idx = c * 256 + lane * 4;
-        if (idx < width) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = v[c][j] - mean;
-                q += d * d;
+        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+            const int idx = c * 256 + lane * 4;
+            if (idx < width) {
+                v[r][c] = *(const f32x4*)(x + row * width + idx);
+                s[r] += v[r][c][0] + v[r][c][1] + v[r][c][2] + v[r][c][3];
             }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + LN_EPS);
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
-        const int idx = c * 256 + lane * 4;
-        if (idx < width) {
-            const f32x4 g = *(const f32x4*)(gamma + idx), b = *(const f32x4*)(beta + idx);
-            f32x4 o;
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t row = row0 + r;
+        const float mean = wave_sum(s[r]) / (float)width;
+        float q = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
-            io<T>::st4(y + row * width + idx, o);
+        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+            const int idx = c * 256 + lane * 4;
+            if (idx < width) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[r][c][j] - mean;
+                    q += d * d;
+                }
+            }
         }
-    }
-    if (lane == 0) {
-        mean_out[row] = mean;
-        rstd_out[row] = rstd;
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + LN_EPS);
+        if (row >= rows) continue;
+#pragma unroll
+        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+            const int idx = c * 256 + lane * 4;
+            if (idx < width) {
+                const f32x4 g = *(const f32x4*)(gamma + idx), b = *(const f32x4*)(beta + idx);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (v[r][c][j] - mean) * rstd * g[j] + b[j];
+                io<T>::st4(y + row * width + idx, o);
+            }
+        }
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
     }
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
-// partial[block][0][w] = sum_rows dy*xhat ; partial[block][1][w] = sum_rows dy
-template <typename T>
+// partial[block][0][w] = sum_rows dy*xhat ; partial[block][1][w] = sum_rows dy ; partial[block][2][w] = sum_rows dx (NSUM == 3)
+template <typename T, int NSUM>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                                             int64_t rows, int width, const float* dres, float* dx, T* dx_cast, float* partial) {
-    __shared__ float red[4 * 2 * LN_MAX_CHUNKS * 256];   // [wave][which][width<=2048]  (64 KiB)
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [wave][which][width]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    f32x4 ag[LN_MAX_CHUNKS], ab[LN_MAX_CHUNKS];
+    f32x4 ag[LN_MAX_CHUNKS], ab[LN_MAX_CHUNKS], ad[LN_MAX_CHUNKS];
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) ag[c] = ab[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) ag[c] = ab[c] = ad[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float invw = 1.0f / (float)width;
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -101,6 +111,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (g[c][j] - s1 - xh[c][j] * s2);
                 if (dres) o += *(const f32x4*)(dres + row * width + idx);
+                if (NSUM == 3) ad[c] += o;
                 *(f32x4*)(dx + row * width + idx) = o;
                 if (dx_cast) io<T>::st4(dx_cast + row * width + idx, o);
             }
@@ -110,29 +121,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
     for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
         const int idx = c * 256 + lane * 4;
         if (idx < width) {
-            *(f32x4*)&red[(w * 2 + 0) * (LN_MAX_CHUNKS * 256) + idx] = ag[c];
-            *(f32x4*)&red[(w * 2 + 1) * (LN_MAX_CHUNKS * 256) + idx] = ab[c];
+            *(f32x4*)&red[(w * NSUM + 0) * width + idx] = ag[c];
+            *(f32x4*)&red[(w * NSUM + 1) * width + idx] = ab[c];
+            if (NSUM == 3) *(f32x4*)&red[(w * NSUM + 2) * width + idx] = ad[c];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * width; i += 256) {
+    for (int i = threadIdx.x; i < NSUM * width; i += 256) {
         const int which = i / width, col = i - which * width;
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) s += red[(ww * 2 + which) * (LN_MAX_CHUNKS * 256) + col];
-        partial[((int64_t)blockIdx.x * 2 + which) * width + col] = s;
+        for (int ww = 0; ww < 4; ++ww) s += red[(ww * NSUM + which) * width + col];
+        partial[((int64_t)blockIdx.x * NSUM + which) * width + col] = s;
     }
 }
 
 // out[which][col] (+)= sum_b partial[b][which][col]     (nwhich slabs of `width` columns per block)
+// 64 columns x 4 row groups per workgroup; the 4 group sums are combined in a fixed order
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1,
-                                                             int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nwhich * width) return;
-    const int which = i / width, col = i - which * width;
+                                                             float* out2, int accumulate) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    const bool live = i < nwhich * width;
+    const int which = live ? i / width : 0, col = live ? i - which * width : 0;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[((int64_t)b * nwhich + which) * width + col];
-    float* out = which == 0 ? out0 : out1;
+    if (live)
+        for (int b = ty; b < nblocks; b += 4) s += partial[((int64_t)b * nwhich + which) * width + col];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || !live) return;
+    s = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+    float* out = which == 0 ? out0 : (which == 1 ? out1 : out2);
     if (!out) return;
     out[col] = accumulate ? out[col] + s : s;
 }
@@ -156,11 +176,17 @@ extern "C" int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, con
     SC_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && width <= LN_MAX_CHUNKS * 256, SC_ERR_SHAPE,
                "sc_layernorm_fwd: width %lld must be a multiple of 4 and <= %d", (long long)width, LN_MAX_CHUNKS * 256);
     SC_REQUIRE(sc_aligned(x, 16) && sc_aligned(y, 8) && sc_aligned(gamma, 16) && sc_aligned(beta, 16), SC_ERR_ALIGN, "sc_layernorm_fwd: misaligned");
-    const dim3 grid((unsigned)sc_cdiv(rows, 4));
-    if (dtype == SC_BF16)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, (int)width, gamma, beta, (bf16_t*)y, mean, rstd);
-    else if (dtype == SC_F32)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, (int)width, gamma, beta, (float*)y, mean, rstd);
+    // narrow rows: 4 rows per wave keep enough bytes in flight; wide rows already fill the registers
+    const bool multi = width <= 1024;
+    const dim3 grid((unsigned)sc_cdiv(rows, multi ? 16 : 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SC_BF16) {
+        if (multi) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (bf16_t*)y, mean, rstd);
+        else hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (bf16_t*)y, mean, rstd);
+    } else if (dtype == SC_F32) {
+        if (multi) hipLaunchKernelGGL((layernorm_fwd_kernel<float, 4>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (float*)y, mean, rstd);
+        else hipLaunchKernelGGL((layernorm_fwd_kernel<float, 1>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (float*)y, mean, rstd);
+    }
     else
         return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_fwd: bad dtype %d", dtype);
     SC_CHECK_LAUNCH();
@@ -168,23 +194,24 @@ extern "C" int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, con
 }
 
 extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
-                                int64_t width, const float* dres, float* dx, void* dx_cast, float* dgamma, float* dbeta, int accumulate,
-                                void* ws, size_t ws_bytes, void* stream) {
+                                int64_t width, const float* dres, float* dx, void* dx_cast, float* dgamma, float* dbeta, float* dx_colsum,
+                                int accumulate, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && gamma && dx, SC_ERR_ARG, "sc_layernorm_bwd: null argument");
     SC_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && width <= LN_MAX_CHUNKS * 256, SC_ERR_SHAPE, "sc_layernorm_bwd: bad width %lld", (long long)width);
     const int nblocks = (int)min((int64_t)RED_MAX_BLOCKS, sc_cdiv(rows, 4));
-    SC_REQUIRE(ws && ws_bytes >= (size_t)nblocks * 2 * width * sizeof(float), SC_ERR_WORKSPACE, "sc_layernorm_bwd: workspace too small");
+    const int nsum = dx_colsum ? 3 : 2;
+    SC_REQUIRE(ws && ws_bytes >= (size_t)nblocks * nsum * width * sizeof(float), SC_ERR_WORKSPACE, "sc_layernorm_bwd: workspace too small");
     SC_REQUIRE(sc_aligned(ws, 16) && sc_aligned(x, 16) && sc_aligned(dx, 16) && sc_aligned(dy, 8), SC_ERR_ALIGN, "sc_layernorm_bwd: misaligned");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SC_BF16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, x, mean, rstd, gamma, rows, (int)width, dres, dx, (bf16_t*)dx_cast, (float*)ws);
-    else if (dtype == SC_F32)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblocks), dim3(256), 0, st, (const float*)dy, x, mean, rstd, gamma, rows, (int)width, dres, dx, (float*)dx_cast, (float*)ws);
-    else
-        return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_bwd: bad dtype %d", dtype);
-    if (dgamma || dbeta)
-        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(2 * width, 256)), dim3(256), 0, st, (const float*)ws, nblocks, 2, (int)width, dgamma,
-                           dbeta, accumulate);
+    const size_t lds_bytes = (size_t)4 * nsum * width * sizeof(float);
+#define LN_BWD(T, NS) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NS>), dim3(nblocks), dim3(256), lds_bytes, st, (const T*)dy, x, mean, rstd, gamma, rows, (int)width, dres, dx, (T*)dx_cast, (float*)ws)
+    if (dtype == SC_BF16) { if (nsum == 3) LN_BWD(bf16_t, 3); else LN_BWD(bf16_t, 2); }
+    else if (dtype == SC_F32) { if (nsum == 3) LN_BWD(float, 3); else LN_BWD(float, 2); }
+    else return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_bwd: bad dtype %d", dtype);
+#undef LN_BWD
+    if (dgamma || dbeta || dx_colsum)
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 64)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,
+                           dbeta, dx_colsum, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
@@ -193,7 +220,7 @@ extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int6
                          void* stream) {
     SC_REQUIRE(x && out && rows > 0 && n > 0, SC_ERR_ARG, "sc_colsum: bad argument");
     SC_REQUIRE(n % 4 == 0 && ld % 4 == 0 && ld >= n, SC_ERR_SHAPE, "sc_colsum: n and ld must be multiples of 4");
-    const int slabs = (int)min((int64_t)RED_MAX_BLOCKS, sc_cdiv(rows, 32));
+    const int slabs = (int)min((int64_t)(n <= 1024 ? RED_MAX_BLOCKS : RED_MAX_BLOCKS / 3), sc_cdiv(rows, 32));
     SC_REQUIRE(ws && ws_bytes >= (size_t)slabs * n * sizeof(float), SC_ERR_WORKSPACE, "sc_colsum: workspace too small");
     const int64_t rpb = sc_cdiv(rows, slabs);
     const int nslab = (int)sc_cdiv(rows, rpb);
@@ -205,8 +232,8 @@ extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int6
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (int)n, ld, rpb, (float*)ws);
     else
         return sc_set_error(SC_ERR_DTYPE, "sc_colsum: bad dtype %d", dtype);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
-                       accumulate);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
+                       (float*)nullptr, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }

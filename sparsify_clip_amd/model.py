@@ -310,6 +310,10 @@ class ClipModel:
                                  ("g_w_fc2", "mlp.c_proj.weight"), ("g_b_fc2", "mlp.c_proj.bias")]:
                 setattr(d, field, self.grad(p + pname).data_ptr())
             tower.descs.append(d)
+        # the c_proj bias gradient of block i-1 is the column sum of block i's dx_in: fused into block i's ln_1 backward
+        for i in range(1, tower.layers):
+            tower.descs[i].g_below_b_fc2 = self.grad(f"{tower.prefix}{i - 1}.mlp.c_proj.bias").data_ptr()
+            tower.descs[i - 1].b_fc2_done = 1
         self._bind_scratch()
 
     def _bind_scratch(self):

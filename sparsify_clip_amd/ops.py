@@ -179,16 +179,16 @@ def layernorm_fwd(x, gamma, beta, out_dtype, out=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_cast=False, dgamma=None, dbeta=None, accumulate=False):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_cast=False, dgamma=None, dbeta=None, accumulate=False, dx_colsum=None):
     rows, w = x.shape
     dx = torch.empty_like(x)
     dx_cast = torch.empty(rows, w, dtype=dy.dtype, device=x.device) if want_cast else None
     if dgamma is None:
         dgamma = torch.zeros(w, dtype=torch.float32, device=x.device)
         dbeta = torch.zeros(w, dtype=torch.float32, device=x.device)
-    ws = _workspace(256 * 2 * w * 4, x.device)
+    ws = _workspace(768 * 3 * w * 4, x.device)
     LIB.call("sc_layernorm_bwd", ptr(dy), sc_dtype(dy.dtype), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), rows, w, ptr(dres), ptr(dx), ptr(dx_cast),
-             ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
+             ptr(dgamma), ptr(dbeta), ptr(dx_colsum), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
     return dx, dx_cast, dgamma, dbeta
 
 
@@ -211,7 +211,7 @@ def colsum(x, out=None, accumulate=False):
     rows, n = x.shape
     if out is None:
         out = torch.zeros(n, dtype=torch.float32, device=x.device)
-    ws = _workspace(256 * n * 4, x.device)
+    ws = _workspace(768 * n * 4, x.device)
     LIB.call("sc_colsum", ptr(x), sc_dtype(x.dtype), rows, n, n, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
     return out
 

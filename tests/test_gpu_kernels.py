@@ -297,8 +297,12 @@ def test_layernorm(ops, dtype, rows, w):
     dy = rnd(rows, w, seed=44).to(dtype)
     dres = rnd(rows, w, seed=45)
     ref.backward(dy.double())
-    dx, dx_cast, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gam.to(DEV), dres=dres.to(DEV), want_cast=True)
+    colsum = torch.ones(w, device=DEV)
+    dx, dx_cast, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gam.to(DEV), dres=dres.to(DEV), want_cast=True, dx_colsum=colsum)
     assert_close(dx, x64.grad + dres.double(), 1e-4, 1e-4, "ln dx")
+    assert_close(colsum, (x64.grad + dres.double()).sum(0), 1e-4, 1e-3, "ln dx column sums (overwrite)")
+    dx2, _, _, _ = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gam.to(DEV))
+    assert_close(dx2, x64.grad, 1e-4, 1e-4, "ln dx without residual")
     assert_close(dx_cast, x64.grad + dres.double(), *tol if dtype == torch.bfloat16 else (1e-4, 1e-4), "ln dx cast")
     assert_close(dg, g64.grad, 1e-4, 1e-3, "ln dgamma")
     assert_close(db, b64.grad, 1e-4, 1e-3, "ln dbeta")
