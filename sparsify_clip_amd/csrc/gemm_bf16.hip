@@ -191,36 +191,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
         _Pragma("unroll") for (int q = 0; q < 2; ++q) glds16(gb[q] + (KT) * KSTEP, bb__ + q * 8 * 128); \
     } while (0)
 
+#define NT256_READ(S, POS, AF, BF)                                                                    \
+    do {                                                                                              \
+        const char* ab__ = smem + (S) * STAGE_BYTES + (wm * 64 + frow) * 128 + (POS);                 \
+        const char* bb__ = smem + (S) * STAGE_BYTES + A_BYTES + (wn * 64 + frow) * 128 + (POS);       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = *(const bf16x8*)(ab__ + i * 16 * 128);  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) BF[i] = *(const bf16x8*)(bb__ + i * 16 * 128);  \
+    } while (0)
+#define NT256_MMA(AF, BF)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j], AF[i], acc[i][j], 0, 0, 0)
+#define NT256_WEAVE()  /* 2 MFMA : 1 LDS read, eight times */                                         \
+    _Pragma("unroll") for (int g__ = 0; g__ < 8; ++g__) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
+    }
+
+    // Software pipeline (one barrier per K-tile, LDS reads always under MFMAs):
+    //   A: MFMAs of k-substep 0 of tile t  ||  LDS reads of substep 1 of tile t
+    //   B: counted vmcnt (tile t+1 landed) + lgkmcnt(0) + barrier   -> stage t%3 is free, stage (t+1)%3 is published
+    //   C: LDS-DMA of tile t+3 into stage t%3 (two tiles stay in flight behind the landed one)
+    //   D: MFMAs of substep 1 of tile t    ||  LDS reads of substep 0 of tile t+1
 #define NT256_BODY(S, KT)                                                                             \
     do {                                                                                              \
-        if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                           \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-        __builtin_amdgcn_s_barrier();                                                                 \
-        if ((KT) + 2 < nk) NT256_STAGE(((S) + 2) % STAGES, (KT) + 2);                                 \
-        const char* ab__ = smem + (S) * STAGE_BYTES + (wm * 64 + frow) * 128;                         \
-        const char* bb__ = smem + (S) * STAGE_BYTES + A_BYTES + (wn * 64 + frow) * 128;               \
-        bf16x8 af__[2][4], bf__[2][4];                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-            af__[0][i] = *(const bf16x8*)(ab__ + i * 16 * 128 + pos0);                                \
-            af__[1][i] = *(const bf16x8*)(ab__ + i * 16 * 128 + pos1);                                \
-            bf__[0][i] = *(const bf16x8*)(bb__ + i * 16 * 128 + pos0);                                \
-            bf__[1][i] = *(const bf16x8*)(bb__ + i * 16 * 128 + pos1);                                \
+        NT256_READ(S, pos1, a1, b1);                                                                  \
+        NT256_MMA(a0, b0);                                                                            \
+        NT256_WEAVE();                                                                                \
+        if ((KT) + 1 < nk) {                                                                          \
+            if ((KT) + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");            \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+            __builtin_amdgcn_s_barrier();                                                             \
+            if ((KT) + 3 < nk) NT256_STAGE(S, (KT) + 3);                                              \
+            NT256_READ(((S) + 1) % STAGES, pos0, a0, b0);                                             \
+            NT256_MMA(a1, b1);                                                                        \
+            NT256_WEAVE();                                                                            \
+        } else {                                                                                      \
+            NT256_MMA(a1, b1);                                                                        \
         }                                                                                             \
-        __builtin_amdgcn_s_setprio(1);                                                                \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf__[s][j], af__[s][i], acc[i][j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                \
     } while (0)
 
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
     NT256_STAGE(0, 0);
     if (nk > 1) NT256_STAGE(1, 1);
+    if (nk > 2) NT256_STAGE(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    NT256_READ(0, pos0, a0, b0);
     for (int kt = 0; kt < nk; kt += STAGES) {
         NT256_BODY(0, kt);
         if (kt + 1 < nk) NT256_BODY(1, kt + 1);
         if (kt + 2 < nk) NT256_BODY(2, kt + 2);
     }
+#undef NT256_WEAVE
+#undef NT256_MMA
+#undef NT256_READ
 #undef NT256_BODY
 #undef NT256_STAGE
 
