@@ -67,18 +67,24 @@ def reference_config(prefix, model, global_batch, precision):
     return key, finalize_config(table[key], 0, {"model": model, "batch_size": global_batch, "precision": precision, "log_every": 1 << 30})
 
 
-def gemm_roofline(model, device):
-    """Replay the bf16 NT GEMM launches of one training step (forward linears + activation-gradient GEMMs of both towers)
-    with a HIP event pair around each launch on the launch stream; algorithmic FLOPs = 2*M*N*K per launch."""
-    from sparsify_clip_amd import ops
+def step_gemm_launches(cfg, batch, k_patch, grid):
+    """(M, N, K) x repetitions of every bf16 NT GEMM launch of one training step (forward linears + activation-gradient GEMMs)."""
     launches = []
-    for tower in (model.visual, model.text):
-        rows, w = tower.batch * tower.seq, tower.width
+    for rows, w, layers in ((batch * (grid ** 2 + 1), cfg["v_width"], cfg["v_layers"]), (batch * cfg["ctx"], cfg["t_width"], cfg["t_layers"])):
         shapes = [(rows, 3 * w, w), (rows, w, w), (rows, 4 * w, w), (rows, w, 4 * w),      # fwd: qkv, out, fc1, fc2
                   (rows, w, 3 * w), (rows, w, w), (rows, w, 4 * w), (rows, 4 * w, w)]      # dX of the same four
-        launches += [(s, tower.layers) for s in shapes]
-    if model.k_pad == model.k_patch:
-        launches.append(((model.visual.batch * model.grid ** 2, model.cfg["v_width"], model.k_patch), 1))
+        launches += [(s, layers) for s in shapes]
+    if k_patch % 64 == 0:
+        launches.append(((batch * grid ** 2, cfg["v_width"], k_patch), 1))
+    return launches
+
+
+def gemm_roofline(model, device):
+    """Replay the bf16 NT GEMM launches of one training step with a HIP event pair around each launch on the launch stream;
+    algorithmic FLOPs = 2*M*N*K per launch.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes over the
+    same launch set (tools/gpu_pmc_traffic.sh: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE), or null when absent."""
+    from sparsify_clip_amd import ops
+    launches = step_gemm_launches(model.cfg, model.visual.batch, model.k_patch, model.grid)
     total_flops, total_ms, count = 0.0, 0.0, 0
     for (m, n, k), reps in launches:
         a = torch.randn(m, k, device=device).to(torch.bfloat16)
@@ -97,8 +103,15 @@ def gemm_roofline(model, device):
         count += reps
         del a, b, out
     achieved = total_flops / (total_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": count,
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            t = json.load(f)
+        if t.get("launches") == count and t.get("local_batch") == model.visual.batch:
+            traffic = t["hbm_bytes_per_launch"]
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": count,
             "avg_launch_us": round(total_ms * 1e3 / count, 1), "flops_per_launch_avg": total_flops / count}
 
 
