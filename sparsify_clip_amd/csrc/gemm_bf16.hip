@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBf16Params p) 
 // the LDS-DMA of K-tile t+2 is issued right after the barrier that publishes tile t, and only a COUNTED vmcnt
 // (the youngest stage, 6 DMA per wave, stays in flight) is waited for - HBM/L2 latency hides under two tiles of MFMAs.
 // The K loop is unrolled by the stage count so every LDS offset is a compile-time constant.
-// Tiles are walked in groups of GROUP_N column tiles inside each XCD's chunk so that the ~32 workgroups an XCD runs
-// at once share 8 A panels and 4 B panels (fits its 4 MiB L2).
-constexpr int T_M = 256, T_N = 128, STAGES = 3, GROUP_N = 4;
+// Tiles are walked band by band (GROUP_M row tiles x all N) inside each XCD's chunk, GROUP_M x GROUP_N cells at a time, so
+// that the ~32 workgroups an XCD runs at once share 8 A panels and 4 B panels and every A panel is fetched once per XCD.
+constexpr int T_M = 256, T_N = 128, STAGES = 3, GROUP_N = 4, GROUP_M = 8;
 constexpr int STAGE_BYTES = (T_M + T_N) * 128;   // 49152
 constexpr int A_BYTES = T_M * 128;
 
@@ -157,12 +157,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD chunk -> grouped (GROUP_N column tiles wide, row-major inside the group) tile order
-    int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int per_group = p.tiles_m * GROUP_N;
-    const int grp = tile / per_group, rem = tile - grp * per_group;
-    const int gw = min(GROUP_N, p.tiles_n - grp * GROUP_N);
-    const int m0 = (rem / gw) * T_M, n0 = (grp * GROUP_N + rem % gw) * T_N;
+    // XCD chunk -> cell order: GROUP_M row tiles x all column tiles form a band (its A panels stay in the XCD's L2 for the
+    // whole sweep over N); inside a band the ~32 resident workgroups cover one GROUP_M x GROUP_N cell at a time.
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int band = tile / (GROUP_M * p.tiles_n), r_band = tile - band * (GROUP_M * p.tiles_n);
+    const int rows = min(GROUP_M, p.tiles_m - band * GROUP_M);
+    const int cell = r_band / (rows * GROUP_N), r_cell = r_band - cell * (rows * GROUP_N);
+    const int gw = min(GROUP_N, p.tiles_n - cell * GROUP_N);
+    const int m0 = (band * GROUP_M + r_cell / gw) * T_M, n0 = (cell * GROUP_N + r_cell % gw) * T_N;
 
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
