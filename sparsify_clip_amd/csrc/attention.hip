@@ -10,6 +10,9 @@
 int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
 int sc_attention_mfma_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                           hipStream_t st);
+int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
+int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                          hipStream_t st);
 
 namespace {
 
@@ -164,7 +167,7 @@ int set_lds(K kernel, size_t bytes) {
 int check(const char* who, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads) {
     SC_REQUIRE(dtype == SC_BF16 || dtype == SC_F32, SC_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
     SC_REQUIRE(batch > 0 && seq > 0 && heads > 0 && width == heads * HD, SC_ERR_SHAPE, "%s: width %lld must be heads*64", who, (long long)width);
-    SC_REQUIRE(seq <= 128, SC_ERR_SHAPE, "%s: sequence length %lld > 128 is not supported by the whole-head-in-LDS kernel", who, (long long)seq);
+    SC_REQUIRE(seq <= (dtype == SC_BF16 ? 272 : 128), SC_ERR_SHAPE, "%s: sequence length %lld is not supported (bf16: <= 272, fp32: <= 128)", who, (long long)seq);
     SC_REQUIRE(batch * heads < (1ll << 31), SC_ERR_SHAPE, "%s: grid too large", who);
     return SC_OK;
 }
@@ -176,7 +179,8 @@ extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t b
     SC_TRY(check("sc_attention_fwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && out, SC_ERR_ARG, "sc_attention_fwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
-        const int rc = sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
+        int rc = sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
+        if (rc == 1) rc = sc_attention_long_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc != 1) return rc;
     }
     const size_t lds = ((size_t)3 * seq * HDP + 4 * 128) * sizeof(float);
@@ -200,7 +204,8 @@ extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv,
     SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
-        const int rc = sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
+        int rc = sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
+        if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc != 1) return rc;
     }
     const size_t lds = ((size_t)4 * seq * HDP + 2 * seq * (seq + 1)) * sizeof(float);

@@ -1,0 +1,285 @@
+// bf16 MFMA attention for the longer sequences (80 < S <= 272: ViT-L/14 has S = 257 image tokens).
+// Same arithmetic and register choreography as attention_mfma.hip (scores of one query row on one lane, accumulator tile
+// fed back as the next MFMA's B operand, transposed operands by ds_read_b64_tr_b16), but one WORKGROUP owns one
+// (batch, head): the K / V (forward) or Q / K / dO (backward) images are shared in LDS by the 4 waves, which split the
+// query tiles (and, in the backward's second pass, the key tiles) between them.  K and V fragments are read from LDS on
+// demand instead of being kept in registers (17 key tiles do not fit).
+#include "attention_mfma_common.h"
+
+namespace {
+
+using namespace attn;
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, float scale) {
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    constexpr int IMG = NT * 16 * LDR;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_fl[];
+    bf16_t* Ks = lds_fl;
+    bf16_t* Vs = Ks + IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 256);
+    stage_head_block(Vs, qb + 2 * W, ld, S, NT * 16, tid, 256);
+    __syncthreads();
+    const int g = lane >> 4, c16 = lane & 15;
+    const int n_it = (S + 15) >> 4;
+    for (int it = wave; it < n_it; it += 4) {
+        const bf16x8 q0 = row_frag_global(qb, ld, it, 0, lane, S), q1 = row_frag_global(qb, ld, it, 1, lane, S);
+        const int i = it * 16 + c16;
+        f32x4 sc[NT + 1];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
+            a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const bool ok = j < S && (!CAUSAL || j <= i);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+                m = fmaxf(m, a[r]);
+            }
+            sc[jt] = a;
+        }
+        sc[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m = group_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[jt][r] - m);
+                sc[jt][r] = p;
+                l += p;
+            }
+        l = group_sum(l);
+        const float inv = 1.0f / l;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 pf = pack_frag(sc[2 * s], sc[2 * s + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vt = (ODD && s == KS - 1) ? tr_frag<false>(Vs, s, 16 * dt, lane) : tr_frag<true>(Vs, s, 16 * dt, lane);
+                o[dt] = MFMA16(vt, pf, o[dt]);
+            }
+        }
+        if (i < S) {
+            bf16_t* op = out + ((int64_t)b * S + i) * W + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(op + 16 * dt, o[dt] * inv);
+        }
+    }
+}
+
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_long_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale) {
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    constexpr int IMG = NT * 16 * LDR;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_bl[];
+    bf16_t* Ks = lds_bl;
+    bf16_t* Qs = Ks + IMG;
+    bf16_t* Os = Qs + IMG;                  // dO
+    float* st_m = (float*)(Os + IMG);
+    float* st_il = st_m + NT * 16;
+    float* st_dl = st_il + NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    const bf16_t* vb = qb + 2 * W;
+    const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
+    bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
+    stage_head_block(Qs, qb, ld, S, NT * 16, tid, 256);
+    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 256);
+    stage_head_block(Os, dob, W, S, NT * 16, tid, 256);
+    __syncthreads();
+    const int g = lane >> 4, c16 = lane & 15;
+    const int n_t = (S + 15) >> 4;
+
+    // ---------------- pass 1: lane = query row i
+    for (int it = wave; it < n_t; it += 4) {
+        const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
+        const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
+        const int i = it * 16 + c16;
+        f32x4 sc[NT + 1], dp[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+            a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
+            a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+            d = MFMA16(row_frag_global(vb, ld, jt, 0, lane, S), g0, d);
+            d = MFMA16(row_frag_global(vb, ld, jt, 1, lane, S), g1, d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const bool ok = j < S && (!CAUSAL || j <= i);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+                m = fmaxf(m, a[r]);
+            }
+            sc[jt] = a;
+            dp[jt] = d;
+        }
+        sc[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m = group_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[jt][r] - m);
+                sc[jt][r] = p;
+                l += p;
+            }
+        l = group_sum(l);
+        const float inv = 1.0f / l;
+        float delta = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[jt][r] *= inv;
+                delta += sc[jt][r] * dp[jt][r];
+            }
+        delta = group_sum(delta);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[jt][r] = sc[jt][r] * (dp[jt][r] - delta) * scale;
+        if (g == 0) {
+            const bool live = i < S;
+            st_m[i] = live ? m : 0.f;
+            st_il[i] = live ? inv : 0.f;
+            st_dl[i] = live ? delta : 0.f;
+        }
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 dsf = pack_frag(sc[2 * s], sc[2 * s + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kt = (ODD && s == KS - 1) ? tr_frag<false>(Ks, s, 16 * dt, lane) : tr_frag<true>(Ks, s, 16 * dt, lane);
+                dq[dt] = MFMA16(kt, dsf, dq[dt]);
+            }
+        }
+        if (i < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
+        }
+    }
+    // tiles of padding queries (none when n_t == NT) must read as "no contribution" in pass 2
+    for (int i = n_t * 16 + tid; i < NT * 16; i += 256) st_m[i] = st_il[i] = st_dl[i] = 0.f;
+    __syncthreads();   // every query tile's statistics are in LDS
+
+    // ---------------- pass 2: lane = key row j
+    for (int jt = wave; jt < n_t; jt += 4) {
+        const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
+        const bf16x8 v0 = row_frag_global(vb, ld, jt, 0, lane, S), v1 = row_frag_global(vb, ld, jt, 1, lane, S);
+        const int j = jt * 16 + c16;
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int it = 2 * s + u;
+                if (ODD && it >= NT) continue;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
+                a = MFMA16(row_frag_lds(Qs, it, 1, lane), k1, a);
+                d = MFMA16(row_frag_lds(Os, it, 0, lane), v0, d);
+                d = MFMA16(row_frag_lds(Os, it, 1, lane), v1, d);
+                const f32x4 mm = *(const f32x4*)(st_m + it * 16 + 4 * g), il = *(const f32x4*)(st_il + it * 16 + 4 * g),
+                            dl = *(const f32x4*)(st_dl + it * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + 4 * g + r;
+                    const bool ok = i < S && j < S && (!CAUSAL || j <= i);
+                    const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
+                    pt[u][r] = p;
+                    dst[u][r] = p * (d[r] - dl[r]) * scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(pt[0], pt[1]), dsf = pack_frag(dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 ot = (ODD && s == KS - 1) ? tr_frag<false>(Os, s, 16 * dt, lane) : tr_frag<true>(Os, s, 16 * dt, lane);
+                const bf16x8 qt = (ODD && s == KS - 1) ? tr_frag<false>(Qs, s, 16 * dt, lane) : tr_frag<true>(Qs, s, 16 * dt, lane);
+                dv[dt] = MFMA16(ot, pf, dv[dt]);
+                dk[dt] = MFMA16(qt, dsf, dk[dt]);
+            }
+        }
+        if (j < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + W + 16 * dt + 4 * g, dk[dt]);
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + 2 * W + 16 * dt + 4 * g, dv[dt]);
+            }
+        }
+    }
+}
+
+template <typename K>
+int reserve_lds(K kernel, size_t bytes) {
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return sc_set_error((int)e, "attention(long): cannot reserve %zu bytes of LDS: %s", bytes, hipGetErrorString(e));
+    }
+    return SC_OK;
+}
+
+constexpr int NT_LONG = 17;   // 272 rows: S <= 272
+
+}  // namespace
+
+// bf16, 80 < seq <= 272.  Returns 1 when the shape is not covered.
+int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+    if (seq > NT_LONG * 16) return 1;
+    const size_t lds = (size_t)2 * NT_LONG * 16 * LDR * sizeof(bf16_t);
+    const dim3 grid((unsigned)(batch * heads));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_fwd_long_kernel<NT_LONG, true>, lds));
+        hipLaunchKernelGGL((attn_fwd_long_kernel<NT_LONG, true>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+    } else {
+        SC_TRY(reserve_lds(attn_fwd_long_kernel<NT_LONG, false>, lds));
+        hipLaunchKernelGGL((attn_fwd_long_kernel<NT_LONG, false>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                          hipStream_t st) {
+    if (seq > NT_LONG * 16) return 1;
+    const size_t lds = ((size_t)3 * NT_LONG * 16 * LDR) * sizeof(bf16_t) + (size_t)3 * NT_LONG * 16 * sizeof(float);
+    const dim3 grid((unsigned)(batch * heads));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_bwd_long_kernel<NT_LONG, true>, lds));
+        hipLaunchKernelGGL((attn_bwd_long_kernel<NT_LONG, true>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width,
+                           (int)heads, 0.125f);
+    } else {
+        SC_TRY(reserve_lds(attn_bwd_long_kernel<NT_LONG, false>, lds));
+        hipLaunchKernelGGL((attn_bwd_long_kernel<NT_LONG, false>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width,
+                           (int)heads, 0.125f);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}

@@ -319,8 +319,10 @@ def _ref_attention(qkv, batch, seq, heads, causal):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (128, 1, False)])
+@pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (128, 1, False), (257, 2, False), (200, 1, True)])
 def test_attention(ops, dtype, seq, heads, causal):
+    if seq > 128 and dtype == torch.float32:
+        pytest.skip("the fp32 (parity-path) attention kernel keeps the whole head in LDS: S <= 128")
     batch, w = 3, heads * 64
     qkv = rnd(batch * seq, 3 * w, seed=51).to(dtype)
     q64 = qkv.double().requires_grad_(True)
@@ -328,7 +330,7 @@ def test_attention(ops, dtype, seq, heads, causal):
     out = ops.attention_fwd(qkv.to(DEV), batch, seq, heads, causal)
     tol = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
     assert_close(out, ref, *tol, "attention fwd")
-    if seq <= 77:
+    if seq <= 77 or (seq > 128 and dtype == torch.bfloat16):
         d_out = rnd(batch * seq, w, seed=52).to(dtype)
         ref.backward(d_out.double())
         d_qkv = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal)

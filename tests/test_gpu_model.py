@@ -69,6 +69,25 @@ def test_towers_forward_backward(pkg, name, precision):
     assert rel_err(model.grad(p), 2 * dict(ref.named_parameters())[p].grad) < gtol
 
 
+def test_vit_l14_geometry_bf16(pkg):
+    """ViT-L/14's geometry (patch 14 -> K = 588 padded to 640 for the GEMM, 257 image tokens -> the block-per-head MFMA
+    attention) at a small width, bf16 against the fp32 oracle."""
+    from oracle.clip_model import synthetic_batch
+    ref, model = _pair(pkg, "test-l14", "bf16")
+    images_np, tokens_np = synthetic_batch(21, 4, ref.cfg)
+    images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+    ei = ref.encode_image(images)
+    di = torch.randn(ei.shape, generator=torch.Generator().manual_seed(6))
+    (ei * di).sum().backward()
+    gi = model.image_forward(images.to(DEV))
+    assert rel_err(gi, ei) < 3e-2
+    model.zero_grad()
+    model.image_backward(di.to(DEV))
+    for pname in ["visual.conv1.weight", "visual.positional_embedding", "visual.transformer.resblocks.0.attn.in_proj_weight",
+                  "visual.transformer.resblocks.0.mlp.c_fc.weight", "visual.proj"]:
+        assert rel_err(model.grad(pname), dict(ref.named_parameters())[pname].grad) < 6e-2, pname
+
+
 def test_autograd_surface_matches_manual(pkg):
     """encode_image/encode_text + the reference-signature loss functions through torch autograd."""
     from oracle.clip_model import synthetic_batch
