@@ -143,7 +143,7 @@ def main():
     from sparsify_clip_amd import dist as D
     rank, local_rank, world = D.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))   # ranks > devices only in the gloo rehearsal
     torch.cuda.set_device(device)
     from sparsify_clip_amd.data import synthetic_batch
     from sparsify_clip_amd.train import Trainer

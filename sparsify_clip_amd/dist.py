@@ -28,7 +28,8 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SC_DIST_BACKEND=gloo rehearses the N > 1 bookkeeping with several ranks on ONE GPU (RCCL refuses duplicate devices)
+            backend = os.environ.get("SC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -60,7 +61,12 @@ def all_gather_embeddings(img_local: torch.Tensor, txt_local: torch.Tensor):
     bl, e = img_local.shape
     fused = torch.cat([img_local, txt_local], dim=1).contiguous()
     out = torch.empty(bl * world_size(), 2 * e, dtype=fused.dtype, device=fused.device)
-    dist.all_gather_into_tensor(out, fused)
+    if dist.get_backend() == "gloo" and fused.is_cuda:   # rehearsal path only: gloo has no CUDA all_gather_into_tensor
+        parts = [torch.empty_like(fused) for _ in range(world_size())]
+        dist.all_gather(parts, fused)
+        out = torch.cat(parts, dim=0)
+    else:
+        dist.all_gather_into_tensor(out, fused)
     return out[:, :e].contiguous(), out[:, e:].contiguous()
 
 

@@ -1,0 +1,71 @@
+"""GPU, 2 ranks on one device over gloo (RCCL refuses duplicate devices, the collective call sites are the same):
+a data-parallel training step (rank-major shards -> embedding all-gather -> replicated global loss -> local gradient rows ->
+bucketed SUM all-reduce -> AdamW) must reproduce the single-process step on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg():
+    from sparsify_clip_amd.config import finalize_config
+    return finalize_config({"project_name": "t", "run_name": "t", "seed": 42, "learning_rate": 1e-3, "batch_size": 8, "model": "tiny",
+                            "num_train_samples": 64, "num_test_samples": 16, "epochs": 1,
+                            "loss_type": "only_lunif_n_then_anchor+lalign+lunif(centroids)", "only_lunif_epochs": 0, "anchor_temperature": 0.1,
+                            "anchor_temperature_learnable": False, "save_checkpoint_every_n_epochs": 20, "resume_checkpoint": False,
+                            "fp16": False}, 0, {"precision": "fp32"})
+
+
+def _batches(steps):
+    from sparsify_clip_amd.data import synthetic_batch
+    return [synthetic_batch(300 + k, 8, 64, 16, 512) for k in range(steps)]
+
+
+def _run(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from sparsify_clip_amd import dist as D
+    from sparsify_clip_amd.model import ClipModel
+    from sparsify_clip_amd.train import Trainer
+    D.init_process_group()
+    torch.cuda.set_device(0)
+    model = ClipModel("tiny", device="cuda:0", precision="fp32", seed=7 + rank)   # different init per rank: the broadcast must fix it
+    tr = Trainer(_cfg(), "cuda:0", 4, model=model)
+    losses = []
+    for images, tokens in _batches(3):
+        a, b = D.shard_bounds(8, rank, world)
+        losses.append(tr.step(images[a:b].cuda(), tokens[a:b].cuda()).item())
+    out[rank] = (losses, model.param("visual.proj").cpu(), model.param("token_embedding.weight").cpu())
+    torch.distributed.destroy_process_group()
+
+
+def test_dp2_step_equals_dp1_step():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sparsify_clip_amd.model import ClipModel
+    from sparsify_clip_amd.train import Trainer
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    ref_model = ClipModel("tiny", device="cuda:0", precision="fp32", seed=7)     # rank 0's initialisation
+    tr = Trainer(_cfg(), "cuda:0", 4, model=ref_model)
+    want = [tr.step(i.cuda(), t.cuda()).item() for i, t in _batches(3)]
+    for rank in (0, 1):
+        losses, proj, emb = out[rank]
+        for got, w in zip(losses, want):
+            assert abs(got - w) <= 2e-5 * abs(w), (rank, losses, want)
+        assert torch.allclose(proj, ref_model.param("visual.proj").cpu(), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(emb, ref_model.param("token_embedding.weight").cpu(), rtol=1e-4, atol=1e-6)
+    assert out[0][0] == out[1][0]      # both ranks evaluate the identical global-batch loss
