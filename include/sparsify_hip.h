@@ -192,6 +192,9 @@ typedef struct sc_block_desc {
     size_t ws_bytes;
     /* optional: the c_proj bias gradient of the block BELOW (= column sums of dx_in), fused into this block's ln_1 backward */
     float* g_below_b_fc2;
+    /* workspace of the weight-gradient side stream of sc_block_bwd_async (same size rule as ws); may be NULL otherwise */
+    void* ws_side;
+    size_t ws_side_bytes;
 } sc_block_desc;
 
 size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype);
@@ -200,6 +203,13 @@ int sc_block_fwd(const sc_block_desc* d, void* stream);
 /* dx_in (fp32 [rows,W]) = (d block / d x_in)^T dx_out; parameter grads into g_*.  dx_out_t / dx_in_t are optional copies
  * of dx_out / dx_in in `dtype` (SC_BF16 only): pass the previous call's dx_in_t as the next call's dx_out_t to skip a cast. */
 int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream);
+/* Same, with the weight-gradient GEMMs (dW = dY^T X) and the bias column sums of d_h / d_qkv enqueued on `side_stream`: they are
+ * off the critical path of the activation gradients, so they overlap the HBM-bound kernels of `stream` (LayerNorm, attention).
+ * Ordering inside the call is by HIP events owned by the library; the CALLER must (a) make `stream` wait for the side work of an
+ * earlier call before a later call reuses the same scratch buffers (d_h, d_qkv, d_res_t, dx_out_t/dx_in_t, ws_side) - i.e. give
+ * consecutive blocks alternating scratch sets - and (b) join `side_stream` before reading the parameter gradients. */
+int sc_block_bwd_async(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream,
+                       void* side_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.AdamW defaults over one flat fp32 parameter buffer (sparsify_clip.py:730, :962/966).

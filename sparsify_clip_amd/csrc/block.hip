@@ -95,19 +95,45 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
     return SC_OK;
 }
 
-extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream) {
+namespace {
+
+// HIP events that order the two streams inside one sc_block_bwd_async call (created once per process, never timed)
+hipEvent_t side_event(int which) {
+    static hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (!ev[which] && hipEventCreateWithFlags(&ev[which], hipEventDisableTiming) != hipSuccess) ev[which] = nullptr;
+    return ev[which];
+}
+
+int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, hipStream_t st, hipStream_t side) {
     SC_TRY(check_desc(d, "sc_block_bwd"));
     SC_REQUIRE(dx_out && dx_in, SC_ERR_ARG, "sc_block_bwd: null gradient buffer");
     SC_REQUIRE(d->d_h && d->d_ln && d->d_qkv && d->d_attn && d->dx_mid && d->ws, SC_ERR_ARG, "sc_block_bwd: null scratch buffer");
     SC_REQUIRE(d->g_ln1_g && d->g_ln1_b && d->g_w_qkv && d->g_b_qkv && d->g_w_o && d->g_b_o && d->g_ln2_g && d->g_ln2_b && d->g_w_fc1 && d->g_b_fc1 &&
                    d->g_w_fc2 && d->g_b_fc2,
                SC_ERR_ARG, "sc_block_bwd: null gradient output");
-    hipStream_t st = (hipStream_t)stream;
     const int64_t rows = d->batch * d->seq, W = d->width, MLP = d->mlp_width;
     const int dt = d->dtype, acc = d->accumulate;
     const bool bf = dt == SC_BF16;
     if (bf) SC_REQUIRE(d->wt_qkv && d->wt_o && d->wt_fc1 && d->wt_fc2 && d->d_res_t, SC_ERR_ARG, "sc_block_bwd: bf16 needs the [in,out] weight copies and d_res_t");
-    SC_REQUIRE(d->ws_bytes >= sc_block_workspace_bytes(rows, W, MLP, dt), SC_ERR_WORKSPACE, "sc_block_bwd: workspace too small");
+    const size_t need = sc_block_workspace_bytes(rows, W, MLP, dt);
+    SC_REQUIRE(d->ws_bytes >= need, SC_ERR_WORKSPACE, "sc_block_bwd: workspace too small");
+    // fp32 path: the GEMM operand of the weight gradients is dx_out itself, which the caller may overwrite in place -> one stream
+    const bool two = side != nullptr && side != st && bf;
+    if (two) SC_REQUIRE(d->ws_side && d->ws_side_bytes >= need, SC_ERR_WORKSPACE, "sc_block_bwd_async: ws_side missing or too small");
+    hipStream_t ss = two ? side : st;                 // stream of the weight-gradient work
+    void* wsw = two ? d->ws_side : d->ws;
+    const size_t wsw_bytes = two ? d->ws_side_bytes : d->ws_bytes;
+    void* stream = (void*)st;
+    int nev = 0;
+    // "everything enqueued on st so far is visible to the side stream"
+    auto publish = [&]() -> int {
+        if (!two) return SC_OK;
+        hipEvent_t e = side_event(nev++ & 3);
+        if (!e) return sc_set_error(SC_ERR_ARG, "sc_block_bwd_async: cannot create a HIP event");
+        hipError_t rc = hipEventRecord(e, st);
+        if (rc == hipSuccess) rc = hipStreamWaitEvent(ss, e, 0);
+        return rc == hipSuccess ? SC_OK : sc_set_error((int)rc, "sc_block_bwd_async: event: %s", hipGetErrorString(rc));
+    };
 
     // GEMM-operand view of dx_out
     const void* g = dx_out;
@@ -119,27 +145,44 @@ extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const v
         }
     }
     // ---- MLP half: c_proj, GELU', c_fc
-    SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, d->ws, d->ws_bytes, st));
-    if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));
+    SC_TRY(publish());
+    SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
+    if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));   // reads the fp32 dx_out: main stream
     EpiParams e = epi_plain();
     e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
-    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, d->ws, d->ws_bytes, st));
-    SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, d->ws, d->ws_bytes, stream));
+    SC_TRY(publish());
+    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
+    SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
-    // dx_mid = dx_out + LN2'(d_ln)
+    // dx_mid = dx_out + LN2'(d_ln); the same kernel emits the operand copy and the out_proj bias gradient (column sums of dx_mid).
+    // With a side stream the copy must not land in the buffer `g` that the side stream may still be reading (internal-cast case).
+    SC_REQUIRE(!(two && bf && g == d->d_res_t), SC_ERR_ARG, "sc_block_bwd_async: pass dx_out_t (the internal cast reuses d_res_t)");
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_mid, d->ln2_mean, d->ln2_rstd, d->ln2_g, rows, W, dx_out, d->dx_mid, bf ? d->d_res_t : nullptr,
-                            d->g_ln2_g, d->g_ln2_b, d->g_b_o /* out_proj bias gradient = column sums of dx_mid */, acc, d->ws, d->ws_bytes, stream));
+                            d->g_ln2_g, d->g_ln2_b, d->g_b_o, acc, d->ws, d->ws_bytes, stream));
     const void* gm = bf ? (const void*)d->d_res_t : (const void*)d->dx_mid;
     // ---- attention half: out_proj, attention, in_proj
-    SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, d->ws, d->ws_bytes, st));
+    SC_TRY(publish());
+    SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
     SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
-    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, d->ws, d->ws_bytes, st));
-    SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
+    SC_TRY(publish());
+    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));
+    SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
     // dx_in = dx_mid + LN1'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,
                             d->g_ln1_b, d->g_below_b_fc2, acc, d->ws, d->ws_bytes, stream));
     return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream) {
+    return block_bwd_impl(d, dx_out, dx_out_t, dx_in, dx_in_t, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int sc_block_bwd_async(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream,
+                                  void* side_stream) {
+    return block_bwd_impl(d, dx_out, dx_out_t, dx_in, dx_in_t, (hipStream_t)stream, (hipStream_t)side_stream);
 }

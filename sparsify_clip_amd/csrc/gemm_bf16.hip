@@ -153,7 +153,7 @@ constexpr int A_BYTES = T_M * 128;
 
 template <bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + 8 * 768];   // + per-wave landing pads of the epilogue prefetch
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -242,47 +242,111 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     NT256_READ(0, pos0, a0, b0);
+    // Epilogue operands: the bias goes to registers and the lines of the GELU' pre-activation / residual tile are pulled
+    // towards L2 by 4-byte LDS-DMA "touches" (no VGPR destination, landing pad in LDS) one K-tile before they are needed.
+    const EpiParams& e = p.epi;
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + ecol;
+    const bool ncol_ok = n < p.N;
+    const int nn = ncol_ok ? n : 0;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    const bool has_pre = e.dgelu_pre != nullptr, has_res = e.resid != nullptr, res_f32 = e.resid_dtype == SC_F32;
+    const int last = nk - 1;
+#define NT256_PREFETCH()                                                                                             \
+    do {                                                                                                             \
+        if (e.bias) { bias0 = *(const f32x4*)(e.bias + nn); bias1 = *(const f32x4*)(e.bias + nn + 4); }               \
+        char* pad__ = smem + STAGES * STAGE_BYTES + wave * 768;                                                      \
+        const int64_t roff__ = (int64_t)min(m0 + wm * 64 + lane, p.M - 1) * e.ld_aux + min(n0 + wn * 64, p.N - 8);    \
+        if (has_pre) __builtin_amdgcn_global_load_lds((gptr_t)((const bf16_t*)e.dgelu_pre + roff__), (lptr_t)pad__, 4, 0, 0); \
+        if (has_res) {                                                                                               \
+            const char* r__ = (const char*)e.resid + roff__ * (res_f32 ? 4 : 2);                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)r__, (lptr_t)(pad__ + 256), 4, 0, 0);                           \
+            if (res_f32 && n0 + wn * 64 + 32 < p.N) __builtin_amdgcn_global_load_lds((gptr_t)(r__ + 128), (lptr_t)(pad__ + 512), 4, 0, 0); \
+        }                                                                                                            \
+    } while (0)
     for (int kt = 0; kt < nk; kt += STAGES) {
+        if (kt == last) NT256_PREFETCH();
         NT256_BODY(0, kt);
-        if (kt + 1 < nk) NT256_BODY(1, kt + 1);
-        if (kt + 2 < nk) NT256_BODY(2, kt + 2);
+        if (kt + 1 < nk) {
+            if (kt + 1 == last) NT256_PREFETCH();
+            NT256_BODY(1, kt + 1);
+        }
+        if (kt + 2 < nk) {
+            if (kt + 2 == last) NT256_PREFETCH();
+            NT256_BODY(2, kt + 2);
+        }
     }
+#undef NT256_PREFETCH
 #undef NT256_WEAVE
 #undef NT256_MMA
 #undef NT256_READ
 #undef NT256_BODY
 #undef NT256_STAGE
 
-    // Epilogue through LDS: each wave parks its 64x64 fp32 sub-tile in its own slab (row stride 68 floats), then walks
-    // it row-major so that every lane owns 8 consecutive columns of one row: bias / GELU / residual loads and the C
-    // store are 16-byte pieces, 8 lanes per 128-B row, instead of 8-byte pieces scattered over 16 rows.
+    // Epilogue.  Every lane owns 8 consecutive columns of 8 rows (row = 8*it + lane/8) of its wave's 64x64 sub-tile.
+    //  1. all global operands of the epilogue (GELU' pre-activation / residual rows, prefetched towards L2 above) are
+    //     requested up front, so at most ONE (L2) latency is exposed per tile instead of one HBM latency per row;
+    //  2. the fp32 accumulators cross over to the row-major ownership through a per-wave LDS slab (row stride 68 floats);
+    //  3. bias / GELU / GELU' / residual are applied on 16-byte pieces and C is stored 16 bytes per lane, 128 B per row.
+    uint4 hpre[8];
+    f32x4 res0[8], res1[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int m = min(m0 + wm * 64 + it * 8 + erow, p.M - 1);
+        const int64_t off = (int64_t)m * e.ld_aux + nn;
+        if (has_pre) hpre[it] = *(const uint4*)((const bf16_t*)e.dgelu_pre + off);
+        if (has_res) {
+            if (res_f32) {
+                res0[it] = *(const f32x4*)((const float*)e.resid + off);
+                res1[it] = *(const f32x4*)((const float*)e.resid + off + 4);
+            } else {
+                res0[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off);
+                res1[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off + 4);
+            }
+        }
+    }
     __syncthreads();   // every wave is done reading the last K-tile
     float* slab = (float*)smem + wave * (64 * 68);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (16 * i + frow) * 68 + 16 * j + 4 * fq) = acc[i][j];
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    const int n = n0 + wn * 64 + ecol;
-    if (n < p.N) {
+    if (ncol_ok) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + erow;
             const int m = m0 + wm * 64 + row;
             if (m >= p.M) continue;
-            const f32x4 v0 = *(const f32x4*)(slab + row * 68 + ecol), v1 = *(const f32x4*)(slab + row * 68 + ecol + 4);
+            f32x4 v0 = *(const f32x4*)(slab + row * 68 + ecol) * e.alpha + bias0;
+            f32x4 v1 = *(const f32x4*)(slab + row * 68 + ecol + 4) * e.alpha + bias1;
+            const int64_t off = (int64_t)m * e.ld_aux + n;
+            if (e.pre_out) {
+                io<bf16_t>::st4((bf16_t*)e.pre_out + off, v0);
+                io<bf16_t>::st4((bf16_t*)e.pre_out + off + 4, v1);
+            }
+            if (e.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v0[j] = gelu_fast(v0[j]); v1[j] = gelu_fast(v1[j]); }
+            }
+            if (has_pre) {
+                const uint4 h = hpre[it];
+                v0[0] *= gelu_grad_fast(__uint_as_float(h.x << 16)); v0[1] *= gelu_grad_fast(__uint_as_float(h.x & 0xffff0000u));
+                v0[2] *= gelu_grad_fast(__uint_as_float(h.y << 16)); v0[3] *= gelu_grad_fast(__uint_as_float(h.y & 0xffff0000u));
+                v1[0] *= gelu_grad_fast(__uint_as_float(h.z << 16)); v1[1] *= gelu_grad_fast(__uint_as_float(h.z & 0xffff0000u));
+                v1[2] *= gelu_grad_fast(__uint_as_float(h.w << 16)); v1[3] *= gelu_grad_fast(__uint_as_float(h.w & 0xffff0000u));
+            }
+            if (has_res) { v0 += res0[it]; v1 += res1[it]; }
             if (OUT_F32) {
                 float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-                const f32x4 r0 = epi_vec4<bf16_t>(p.epi, v0, m, n, cp), r1 = epi_vec4<bf16_t>(p.epi, v1, m, n + 4, cp + 4);
-                *(f32x4*)cp = r0;
-                *(f32x4*)(cp + 4) = r1;
+                if (e.beta != 0.f) { v0 += *(const f32x4*)cp * e.beta; v1 += *(const f32x4*)(cp + 4) * e.beta; }
+                *(f32x4*)cp = v0;
+                *(f32x4*)(cp + 4) = v1;
             } else {
-                const f32x4 r0 = epi_vec4<bf16_t>(p.epi, v0, m, n, nullptr), r1 = epi_vec4<bf16_t>(p.epi, v1, m, n + 4, nullptr);
                 uint4 u;
-                u.x = (unsigned)f32_to_bf16(r0[0]) | ((unsigned)f32_to_bf16(r0[1]) << 16);
-                u.y = (unsigned)f32_to_bf16(r0[2]) | ((unsigned)f32_to_bf16(r0[3]) << 16);
-                u.z = (unsigned)f32_to_bf16(r1[0]) | ((unsigned)f32_to_bf16(r1[1]) << 16);
-                u.w = (unsigned)f32_to_bf16(r1[2]) | ((unsigned)f32_to_bf16(r1[3]) << 16);
+                u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
+                u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
+                u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
+                u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
                 *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
             }
         }
@@ -414,6 +478,158 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, 256x128, 3-stage
+// Same pipeline as the NT 256x128 kernel (3 LDS stages, counted vmcnt, one barrier per 64-row step, LDS reads woven under
+// the MFMAs); a stage holds three [64 r][128 cols] images with 256-B rows (two for the 256 columns of A, one for B), all
+// with the 32-B slot swizzle of tn_swz, read back transposed by ds_read_b64_tr_b16.  The contraction is split over
+// workgroups so that tiles x splits fills the chip once (<= 256 workgroups, one per CU: no tail round).
+constexpr int TN_IMG = 16384;   // one [64][128] bf16 image
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, ntiles * p.splits);
+    const int split = id / ntiles, tile = id % ntiles;
+    const int m0 = (tile / p.tiles_n) * T_M, n0 = (tile % p.tiles_n) * T_N;
+    const int kt_begin = split * p.k_per_split;
+    const int nk_total = (p.K + KSTEP - 1) / KSTEP;
+    const int kt_end = min(nk_total, kt_begin + p.k_per_split);
+    const int nk = kt_end - kt_begin;
+
+    // staging: per image 16 wave instructions of 4 rows x 256 B; wave w takes instructions 2w and 2w+1 of every image
+    const int srow = lane >> 4;
+    int col_a0[2], col_a1[2], col_b[2], rowq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wave * 2 + q) * 4 + srow;
+        const int c = (lane & 15) ^ tn_swz(r);
+        rowq[q] = r;
+        col_a0[q] = min(m0 + c * 8, p.M - 8);
+        col_a1[q] = min(m0 + 128 + c * 8, p.M - 8);
+        col_b[q] = min(n0 + c * 8, p.N - 8);
+    }
+#define TN256_STAGE(S, KT)                                                                                      \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                         \
+            const int64_t gr__ = min((kt_begin + (KT)) * KSTEP + rowq[q], p.K - 1);                             \
+            char* dst__ = smem + (S) * STAGE_BYTES + (wave * 2 + q) * 1024;                                     \
+            glds16(p.A + gr__ * p.lda + col_a0[q], dst__);                                                      \
+            glds16(p.A + gr__ * p.lda + col_a1[q], dst__ + TN_IMG);                                             \
+            glds16(p.B + gr__ * p.ldb + col_b[q], dst__ + 2 * TN_IMG);                                          \
+        }                                                                                                       \
+    } while (0)
+    // rows past the contraction length contribute zero (their clamped loads fetched a valid row): executed by every wave
+    // between the barrier that publishes the stage and the first read, followed by its own barrier (last step only)
+#define TN256_ZERO_TAIL(S, KT)                                                                                  \
+    do {                                                                                                        \
+        const int valid__ = p.K - (kt_begin + (KT)) * KSTEP;                                                    \
+        if (valid__ < KSTEP) {                                                                                  \
+            for (int piece = t; piece < 3 * 1024; piece += 512) {                                               \
+                const int row = (piece & 1023) >> 4;                                                            \
+                if (row >= valid__) *(uint4*)(smem + (S) * STAGE_BYTES + piece * 16) = uint4{0u, 0u, 0u, 0u};   \
+            }                                                                                                   \
+            __syncthreads();                                                                                    \
+        }                                                                                                       \
+    } while (0)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    const int swz = (q4 | ((g & 1) << 2)) << 1;
+    const int a_img = (wm >> 1) * TN_IMG, a_col = (wm & 1) * 64, b_col = wn * 64;
+    // fragments of k-substep SUB (0/1) of stage S: element e <-> row 32*SUB + 8g + e
+#define TN256_READ(S, SUB, AF, BF)                                                                              \
+    do {                                                                                                        \
+        const char* st__ = smem + (S) * STAGE_BYTES;                                                            \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                         \
+            const int row = 32 * (SUB) + 8 * g + 4 * h + q4;                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+                const int ca = ((a_col + 16 * i) >> 3) + (pp >> 1), cb = ((b_col + 16 * i) >> 3) + (pp >> 1);   \
+                const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(st__ + a_img + row * 256 + ((ca ^ swz) << 4) + ((pp & 1) << 3))); \
+                const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(st__ + 2 * TN_IMG + row * 256 + ((cb ^ swz) << 4) + ((pp & 1) << 3))); \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) { AF[i][4 * h + e] = va[e]; BF[i][4 * h + e] = vb[e]; } \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+#define TN256_MMA(AF, BF)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j], AF[i], acc[i][j], 0, 0, 0)
+#define TN256_WEAVE()                                                                                           \
+    _Pragma("unroll") for (int g__ = 0; g__ < 16; ++g__) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+    }
+#define TN256_BODY(S, KT)                                                                                       \
+    do {                                                                                                        \
+        TN256_READ(S, 1, a1, b1);                                                                               \
+        TN256_MMA(a0, b0);                                                                                      \
+        TN256_WEAVE();                                                                                          \
+        if ((KT) + 1 < nk) {                                                                                    \
+            if ((KT) + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                      \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_s_barrier();                                                                       \
+            if ((KT) + 3 < nk) TN256_STAGE(S, (KT) + 3);                                                        \
+            if ((KT) + 2 == nk) TN256_ZERO_TAIL(((S) + 1) % STAGES, (KT) + 1);                                  \
+            TN256_READ(((S) + 1) % STAGES, 0, a0, b0);                                                          \
+            TN256_MMA(a1, b1);                                                                                  \
+            TN256_WEAVE();                                                                                      \
+        } else {                                                                                                \
+            TN256_MMA(a1, b1);                                                                                  \
+        }                                                                                                       \
+    } while (0)
+
+    if (nk > 0) {
+        bf16x8 a0[4], b0[4], a1[4], b1[4];
+        TN256_STAGE(0, 0);
+        if (nk > 1) TN256_STAGE(1, 1);
+        if (nk > 2) TN256_STAGE(2, 2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nk == 1) TN256_ZERO_TAIL(0, 0);
+        TN256_READ(0, 0, a0, b0);
+        for (int kt = 0; kt < nk; kt += STAGES) {
+            TN256_BODY(0, kt);
+            if (kt + 1 < nk) TN256_BODY(1, kt + 1);
+            if (kt + 2 < nk) TN256_BODY(2, kt + 2);
+        }
+    }
+#undef TN256_BODY
+#undef TN256_WEAVE
+#undef TN256_MMA
+#undef TN256_READ
+#undef TN256_ZERO_TAIL
+#undef TN256_STAGE
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + i16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * g;
+            if (n >= p.N) continue;
+            if (p.partial) {
+                *(f32x4*)(p.partial + ((int64_t)split * p.M + m) * p.N + n) = acc[i][j];
+            } else {
+                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                f32x4 v = acc[i][j] * p.epi.alpha;
+                if (p.epi.beta != 0.f) v += *(const f32x4*)cp * p.epi.beta;
+                *(f32x4*)cp = v;
+            }
+        }
+    }
+}
+
 // C = alpha * sum_s partial[s] + beta * C   (fixed order)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, int64_t mn, int n, float* c, int64_t ldc,
                                                             float alpha, float beta) {
@@ -427,10 +643,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
     *(f32x4*)cp = v;
 }
 
+bool tn_small() {
+    // default: the 128x128 2-stage kernel at 2 workgroups/CU (600-700 TF); SC_GEMM_TN=256 selects the 256x128 3-stage variant,
+    // which measured 540-650 TF on the same shapes (both are load-latency bound: SQ_WAIT_ANY 63 %, LDS conflicts 0)
+    static const bool v = [] { const char* e = getenv("SC_GEMM_TN"); return !(e && e[0] == '2'); }();
+    return v;
+}
+
 int tn_splits(int64_t m, int64_t n, int64_t r) {
-    const int64_t tiles = sc_cdiv(m, TILE) * sc_cdiv(n, TILE);
     const int64_t nk = sc_cdiv(r, KSTEP);
-    int64_t s = sc_cdiv(768, tiles);
+    int64_t s;
+    if (tn_small()) {
+        s = sc_cdiv(768, sc_cdiv(m, TILE) * sc_cdiv(n, TILE));
+    } else {
+        const int64_t tiles = sc_cdiv(m, T_M) * sc_cdiv(n, T_N);
+        s = 256 / tiles;   // fill the 256 CUs once: no partially filled second round
+    }
     const int64_t cap = nk / 4 > 1 ? nk / 4 : 1;
     if (s > cap) s = cap;
     if (s > 32) s = 32;
@@ -488,7 +716,8 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)r;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
+    const bool small = tn_small();
+    p.tiles_m = (int)sc_cdiv(m, small ? TILE : T_M); p.tiles_n = (int)sc_cdiv(n, small ? TILE : T_N);
     p.splits = tn_splits(m, n, r);
     const int64_t nk = sc_cdiv(r, KSTEP);
     p.k_per_split = (int)sc_cdiv(nk, p.splits);
@@ -501,7 +730,8 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
         p.partial = (float*)ws;
     }
     const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n * p.splits);
-    hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+    if (small) hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3(grid), dim3(512), 0, stream, p);
     SC_CHECK_LAUNCH();
     if (p.splits > 1) {
         const int64_t mn = m * n;

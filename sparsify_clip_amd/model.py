@@ -93,6 +93,7 @@ class ClipModel:
         self._grads_fresh = True   # next backward overwrites (True) or accumulates (False)
         self.comm = None      # optional data-parallel hook (dist.GradSync)
         self._scratch = {}
+        self._side = None      # side stream of the weight-gradient GEMMs (bf16 path)
         self.init_parameters(seed)
 
     # ------------------------------------------------------------------------------------------ layout
@@ -283,8 +284,14 @@ class ClipModel:
             b[key] = [torch.empty(rows, dtype=f32, device=dev) for _ in range(tower.layers)]
         # backward scratch shared by both towers (sized for the larger request)
         ws_bytes = ops.block_workspace_bytes(rows, w, mlp, T)
-        sc = {"d_h": (rows * mlp, T), "d_ln": (rows * w, T), "d_qkv": (rows * 3 * w, T), "d_attn": (rows * w, T), "d_res_t": (rows * w, T),
-              "dx_mid": (rows * w, f32), "dx": (rows * w, f32), "dx_t": (rows * w, T), "ws": (ws_bytes, torch.uint8)}
+        # the weight-gradient side stream of block k may still read d_h / d_qkv / d_res_t / dx_t while block k+1 runs on the main
+        # stream: those live in two (dx_t: three) rotating sets, the rest is shared
+        sc = {"d_ln": (rows * w, T), "d_attn": (rows * w, T), "dx_mid": (rows * w, f32), "dx": (rows * w, f32), "ws": (ws_bytes, torch.uint8),
+              "ws_side": (ws_bytes, torch.uint8)}
+        for k in range(2):
+            sc.update({f"d_h.{k}": (rows * mlp, T), f"d_qkv.{k}": (rows * 3 * w, T), f"d_res_t.{k}": (rows * w, T)})
+        for k in range(3):
+            sc[f"dx_t.{k}"] = (rows * w, T)
         for key, (n, dt) in sc.items():
             cur = self._scratch.get("bwd." + key)
             if cur is None or cur.numel() < n or cur.dtype != dt:
@@ -320,10 +327,14 @@ class ClipModel:
 
     def _bind_scratch(self):
         for tower in (self.visual, self.text):
-            for d in tower.descs:
-                for key in ["d_h", "d_ln", "d_qkv", "d_attn", "d_res_t", "dx_mid", "ws"]:
+            for i, d in enumerate(tower.descs):
+                k = (tower.layers - 1 - i) % 2          # position in the backward order selects the scratch set
+                for key in ["d_ln", "d_attn", "dx_mid", "ws", "ws_side"]:
                     setattr(d, key, self._scratch["bwd." + key].data_ptr())
+                for key in ["d_h", "d_qkv", "d_res_t"]:
+                    setattr(d, key, self._scratch[f"bwd.{key}.{k}"].data_ptr())
                 d.ws_bytes = self._scratch["bwd.ws"].numel()
+                d.ws_side_bytes = self._scratch["bwd.ws_side"].numel()
 
     # ------------------------------------------------------------------------------------------ towers
     def _linear(self, x, w):
@@ -337,17 +348,44 @@ class ClipModel:
             ops.block_fwd(d)
 
     def _blocks_bwd(self, tower, dx, acc):
-        """dx: fp32 [rows,W] gradient w.r.t. the last block's output; returns gradient w.r.t. the first block's input (in place)."""
+        """dx: fp32 [rows,W] gradient w.r.t. the last block's output; returns gradient w.r.t. the first block's input (in place).
+
+        bf16: the weight-gradient GEMMs of block k run on a side stream (sc_block_bwd_async) and overlap the HBM-bound kernels
+        of block k+1 on the main stream; block k+2 reuses block k's scratch set, so it first waits for block k's side work
+        (that is also the moment block k's gradient bucket is handed to the all-reduce)."""
         bf = self.dtype == torch.bfloat16
-        dx_t = self._scratch["bwd.dx_t"] if bf else None
-        have_t = False
-        for i in reversed(range(tower.layers)):
+        if not bf:
+            for i in reversed(range(tower.layers)):
+                d = tower.descs[i]
+                d.accumulate = int(acc)
+                ops.block_bwd(d, dx, None, dx, None)
+                if self.comm is not None:
+                    self.comm.bucket_ready(f"{tower.prefix}{i}.")
+            return dx
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_done = [torch.cuda.Event(), torch.cuda.Event()]
+        n = dx.numel()
+        dx_t = [self._scratch[f"bwd.dx_t.{k}"][:n] for k in range(3)]
+        ops.cast_bf16(dx, dx_t[0])
+        self._side.wait_stream(main)                      # everything the side stream will read exists
+        pending = []                                      # (step, layer) whose side work has not been joined yet
+        for step, i in enumerate(reversed(range(tower.layers))):
+            if step >= 2:
+                main.wait_event(self._side_done[step % 2])           # block (step-2) is done with this scratch set
+                s0, layer0 = pending.pop(0)
+                if self.comm is not None:
+                    self.comm.bucket_ready(f"{tower.prefix}{layer0}.")
             d = tower.descs[i]
             d.accumulate = int(acc)
-            ops.block_bwd(d, dx, dx_t if (bf and have_t) else None, dx, dx_t)
-            have_t = True
+            ops.block_bwd(d, dx, dx_t[step % 3], dx, dx_t[(step + 1) % 3], side_stream=self._side)
+            self._side_done[step % 2].record(self._side)
+            pending.append((step, i))
+        main.wait_stream(self._side)
+        for _, layer0 in pending:
             if self.comm is not None:
-                self.comm.bucket_ready(f"{tower.prefix}{i}.")
+                self.comm.bucket_ready(f"{tower.prefix}{layer0}.")
         return dx
 
     def image_forward(self, images):

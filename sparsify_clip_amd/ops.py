@@ -303,5 +303,9 @@ def block_fwd(desc: BlockDesc):
     LIB.call("sc_block_fwd", ctypes.byref(desc), stream_ptr())
 
 
-def block_bwd(desc: BlockDesc, dx_out, dx_out_t, dx_in, dx_in_t):
-    LIB.call("sc_block_bwd", ctypes.byref(desc), ptr(dx_out), ptr(dx_out_t), ptr(dx_in), ptr(dx_in_t), stream_ptr())
+def block_bwd(desc: BlockDesc, dx_out, dx_out_t, dx_in, dx_in_t, side_stream=None):
+    if side_stream is None:
+        LIB.call("sc_block_bwd", ctypes.byref(desc), ptr(dx_out), ptr(dx_out_t), ptr(dx_in), ptr(dx_in_t), stream_ptr())
+    else:
+        LIB.call("sc_block_bwd_async", ctypes.byref(desc), ptr(dx_out), ptr(dx_out_t), ptr(dx_in), ptr(dx_in_t), stream_ptr(),
+                 ctypes.c_void_p(side_stream.cuda_stream))

@@ -1,0 +1,4 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p $R/gpurun_out; cd $R; export TMPDIR=/tmp
+timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 200 -p no:cacheprovider -k "gemm" > gpurun_out/pytest_gemm.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gemm.log
+timeout -k 10 300 python tools/epi_bench.py 2>&1 | tee gpurun_out/epi_bench.log
