@@ -137,21 +137,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
 }
 
 // out[which][col] (+)= sum_b partial[b][which][col]     (nwhich slabs of `width` columns per block)
-// 64 columns x 4 row groups per workgroup; the 4 group sums are combined in a fixed order
+// 16 columns x 16 row groups per workgroup (many small workgroups: the slabs are L2-resident and this kernel is latency-
+// bound); the 16 group sums are combined in a fixed order
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1,
                                                              float* out2, int accumulate) {
-    __shared__ float sm[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tx;
+    __shared__ float sm[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + tx;
     const bool live = i < nwhich * width;
     const int which = live ? i / width : 0, col = live ? i - which * width : 0;
     float s = 0.f;
     if (live)
-        for (int b = ty; b < nblocks; b += 4) s += partial[((int64_t)b * nwhich + which) * width + col];
+        for (int b = ty; b < nblocks; b += 16) s += partial[((int64_t)b * nwhich + which) * width + col];
     sm[ty][tx] = s;
     __syncthreads();
     if (ty != 0 || !live) return;
-    s = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k][tx];
     float* out = which == 0 ? out0 : (which == 1 ? out1 : out2);
     if (!out) return;
     out[col] = accumulate ? out[col] + s : s;
@@ -210,7 +213,7 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
     else return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_bwd: bad dtype %d", dtype);
 #undef LN_BWD
     if (dgamma || dbeta || dx_colsum)
-        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 64)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 16)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,
                            dbeta, dx_colsum, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -232,7 +235,7 @@ extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int6
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (int)n, ld, rpb, (float*)ws);
     else
         return sc_set_error(SC_ERR_DTYPE, "sc_colsum: bad dtype %d", dtype);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
                        (float*)nullptr, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;

@@ -292,10 +292,10 @@ class ClipModel:
             sc.update({f"d_h.{k}": (rows * mlp, T), f"d_qkv.{k}": (rows * 3 * w, T), f"d_res_t.{k}": (rows * w, T)})
         for k in range(3):
             sc[f"dx_t.{k}"] = (rows * w, T)
-        for key, (n, dt) in sc.items():
-            cur = self._scratch.get("bwd." + key)
+        for key, (n, dt) in sc.items():       # one scratch family per tower: their backward passes run on different streams
+            cur = self._scratch.get(f"bwd.{tower.kind}.{key}")
             if cur is None or cur.numel() < n or cur.dtype != dt:
-                self._scratch["bwd." + key] = torch.empty(n, dtype=dt, device=dev)
+                self._scratch[f"bwd.{tower.kind}.{key}"] = torch.empty(n, dtype=dt, device=dev)
         tower.batch = batch
         tower.descs = []
         for i in range(tower.layers):
@@ -329,12 +329,13 @@ class ClipModel:
         for tower in (self.visual, self.text):
             for i, d in enumerate(tower.descs):
                 k = (tower.layers - 1 - i) % 2          # position in the backward order selects the scratch set
+                fam = f"bwd.{tower.kind}."
                 for key in ["d_ln", "d_attn", "dx_mid", "ws", "ws_side"]:
-                    setattr(d, key, self._scratch["bwd." + key].data_ptr())
+                    setattr(d, key, self._scratch[fam + key].data_ptr())
                 for key in ["d_h", "d_qkv", "d_res_t"]:
-                    setattr(d, key, self._scratch[f"bwd.{key}.{k}"].data_ptr())
-                d.ws_bytes = self._scratch["bwd.ws"].numel()
-                d.ws_side_bytes = self._scratch["bwd.ws_side"].numel()
+                    setattr(d, key, self._scratch[f"{fam}{key}.{k}"].data_ptr())
+                d.ws_bytes = self._scratch[fam + "ws"].numel()
+                d.ws_side_bytes = self._scratch[fam + "ws_side"].numel()
 
     # ------------------------------------------------------------------------------------------ towers
     def _linear(self, x, w):
@@ -364,25 +365,27 @@ class ClipModel:
             return dx
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._side_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._side = {}
+        if tower.kind not in self._side:
+            self._side[tower.kind] = (torch.cuda.Stream(device=self.device), [torch.cuda.Event(), torch.cuda.Event()])
+        side, side_done = self._side[tower.kind]
         n = dx.numel()
-        dx_t = [self._scratch[f"bwd.dx_t.{k}"][:n] for k in range(3)]
+        dx_t = [self._scratch[f"bwd.{tower.kind}.dx_t.{k}"][:n] for k in range(3)]
         ops.cast_bf16(dx, dx_t[0])
-        self._side.wait_stream(main)                      # everything the side stream will read exists
+        side.wait_stream(main)                            # everything the side stream will read exists
         pending = []                                      # (step, layer) whose side work has not been joined yet
         for step, i in enumerate(reversed(range(tower.layers))):
             if step >= 2:
-                main.wait_event(self._side_done[step % 2])           # block (step-2) is done with this scratch set
+                main.wait_event(side_done[step % 2])                 # block (step-2) is done with this scratch set
                 s0, layer0 = pending.pop(0)
                 if self.comm is not None:
                     self.comm.bucket_ready(f"{tower.prefix}{layer0}.")
             d = tower.descs[i]
             d.accumulate = int(acc)
-            ops.block_bwd(d, dx, dx_t[step % 3], dx, dx_t[(step + 1) % 3], side_stream=self._side)
-            self._side_done[step % 2].record(self._side)
+            ops.block_bwd(d, dx, dx_t[step % 3], dx, dx_t[(step + 1) % 3], side_stream=side)
+            side_done[step % 2].record(side)
             pending.append((step, i))
-        main.wait_stream(self._side)
+        main.wait_stream(side)
         for _, layer0 in pending:
             if self.comm is not None:
                 self.comm.bucket_ready(f"{tower.prefix}{layer0}.")
@@ -427,7 +430,7 @@ class ClipModel:
                                               dgamma=self.grad("visual.ln_post.weight"), dbeta=self.grad("visual.ln_post.bias"), accumulate=acc)
         if self.comm is not None:
             self.comm.bucket_ready("visual.head")
-        dx = self._scratch["bwd.dx"][: batch * tw.seq * tw.width].view(batch * tw.seq, tw.width)
+        dx = self._scratch["bwd.image.dx"][: batch * tw.seq * tw.width].view(batch * tw.seq, tw.width)
         dx.zero_()
         ops.pool_scatter(d_pooled, None, batch, tw.seq, dx)
         self._blocks_bwd(tw, dx, acc)
@@ -475,7 +478,7 @@ class ClipModel:
                                               dgamma=self.grad("ln_final.weight"), dbeta=self.grad("ln_final.bias"), accumulate=acc)
         if self.comm is not None:
             self.comm.bucket_ready("text.head")
-        dx = self._scratch["bwd.dx"][: batch * tw.seq * tw.width].view(batch * tw.seq, tw.width)
+        dx = self._scratch["bwd.text.dx"][: batch * tw.seq * tw.width].view(batch * tw.seq, tw.width)
         dx.zero_()
         ops.pool_scatter(d_pooled, b["eot"], batch, tw.seq, dx)
         self._blocks_bwd(tw, dx, acc)

@@ -15,8 +15,8 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
-    """Grow-only byte workspace per (device, tag); reused across calls on the same stream."""
-    key = (str(device), tag)
+    """Grow-only byte workspace per (device, tag, stream); reused across calls on the same stream."""
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream)   # one workspace per stream: the towers run concurrently
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

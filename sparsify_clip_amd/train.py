@@ -78,13 +78,22 @@ class Trainer:
         self.current_batch, self.epoch = 0, 0
         self.beta, self.alpha = 0.0, 0.0    # :743-744
         self.pending_logs = []
+        self.text_stream = None
 
     def step(self, images, captions):
         cfg, m = self.config, self.model
         self.current_batch += 1                                                    # :755
         tokens = captions if isinstance(captions, torch.Tensor) else self.tokenizer(captions)   # :762
+        # the two towers are independent until the loss head: the text tower runs on its own HIP stream so that its HBM-bound
+        # kernels (LayerNorm, attention, embedding) overlap the image tower's GEMMs and vice versa
+        main = torch.cuda.current_stream()
+        if self.text_stream is None:
+            self.text_stream = torch.cuda.Stream(device=self.device)
+        self.text_stream.wait_stream(main)
+        with torch.cuda.stream(self.text_stream):
+            txt_e = m.text_forward(tokens)                                         # :769
         img_e = m.image_forward(images)                                            # :768
-        txt_e = m.text_forward(tokens)                                             # :769
+        main.wait_stream(self.text_stream)
         img_n, inv_i = ops.l2norm_fwd(img_e, 0.0)                                  # :772
         txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0)                                  # :773
         img_all, txt_all = D.all_gather_embeddings(img_n, txt_n)
@@ -103,8 +112,11 @@ class Trainer:
         self.optimizer.zero_grad()                                                 # :957
         d_img_e = ops.l2norm_bwd(img_n, inv_i, D.local_rows(res.d_img))
         d_txt_e = ops.l2norm_bwd(txt_n, inv_t, D.local_rows(res.d_txt))
-        m.image_backward(d_img_e)                                                  # :965
-        m.text_backward(d_txt_e)
+        self.text_stream.wait_stream(main)          # loss.backward() (:965): the two towers' backward passes are independent too
+        with torch.cuda.stream(self.text_stream):
+            m.text_backward(d_txt_e)
+        m.image_backward(d_img_e)
+        main.wait_stream(self.text_stream)
         if self.learnable_t and res.d_temp is not None:
             self.temperature.grad = res.d_temp.detach().cpu().reshape(())
         self.sync.wait_all()
