@@ -191,3 +191,38 @@ def test_evaluate_and_state_dict(pkg):
     other = pkg.ClipModel("tiny", device=DEV, precision="bf16", seed=1)
     other.load_state_dict(sd)
     assert torch.equal(other.param("text_projection"), model.param("text_projection"))
+
+
+def test_c1_vit_b32_batch32_step_parity_fp32(pkg):
+    """BASELINE config #1 at its real size: experiment_1 (anchor loss, learnable temperature) on ViT-B/32, batch 32 - two
+    training steps on the fp32 path against the oracle's CPU step, per-step loss within 1e-4 relative; then the same batch on
+    the bf16 path within its looser documented bound."""
+    from conftest import load_json
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if "experiment_1-" in k][0]]
+    cfg = finalize_config(raw, 0, {"model": "ViT-B-32", "batch_size": 32, "precision": "fp32", "epochs": 1})
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = create_model("ViT-B-32", seed=5)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    cpu = CpuTrainer(cfg, 10, model=ref)
+    model = pkg.ClipModel("ViT-B-32", device=DEV, precision="fp32")
+    model.load_state_dict(sd)
+    gpu = Trainer(cfg, DEV, 10, model=model)
+    first = None
+    for k in range(2):
+        images_np, tokens_np = synthetic_batch(500 + k, 32, ref.cfg)
+        images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+        want = cpu.step(images, tokens).item()
+        got = gpu.step(images.to(DEV), tokens.to(DEV)).item()
+        assert abs(got - want) <= 1e-4 * abs(want), (k, got, want)
+        first = first if first is not None else (images, tokens, want)
+    del model, gpu
+    torch.cuda.empty_cache()
+    bf = pkg.ClipModel("ViT-B-32", device=DEV, precision="bf16")
+    bf.load_state_dict(sd)
+    got = Trainer(dict(cfg, precision="bf16"), DEV, 10, model=bf).step(first[0].to(DEV), first[1].to(DEV)).item()
+    assert abs(got - first[2]) <= 2e-2 * abs(first[2]), (got, first[2])
