@@ -484,12 +484,14 @@ class ClipModel:
         self._blocks_bwd(tw, dx, acc)
         # token-embedding scatter-add in a fixed order: positions after EOT carry an exactly-zero gradient under the
         # causal mask and are left out; the index sort is bookkeeping (torch), the fp32 sums are the HIP kernel's.
+        # No host sync here (a .nonzero() would stall the enqueue of the other tower): inactive positions get the key `vocab`,
+        # sort to the end, and the scatter kernel ignores keys outside [0, vocab).
         tokens = b["tokens"]
         pos_idx = torch.arange(tw.seq, device=self.device, dtype=torch.int32)
-        active = (pos_idx[None, :] <= b["eot"][:, None]).reshape(-1).nonzero().squeeze(1)
-        st, perm = torch.sort(tokens.reshape(-1)[active], stable=True)
-        ops.text_embed_bwd(dx, st.contiguous(), active[perm].contiguous(), batch, tw.seq, self.grad("token_embedding.weight"),
-                           self.grad("positional_embedding"), acc)
+        active = pos_idx[None, :] <= b["eot"][:, None]
+        keys = torch.where(active, tokens, torch.full_like(tokens, self.cfg["vocab"])).reshape(-1)
+        st, order = torch.sort(keys, stable=True)
+        ops.text_embed_bwd(dx, st, order, batch, tw.seq, self.grad("token_embedding.weight"), self.grad("positional_embedding"), acc)
         if self.comm is not None:
             self.comm.bucket_ready("text.stem")
 
