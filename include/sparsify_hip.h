@@ -122,7 +122,7 @@ int sc_retrieval_ranks(const float* score, int64_t n, int32_t* rank_fwd, int32_t
 /* LayerNorm(eps 1e-5, affine) over rows of a fp32 [rows,width] matrix -> y (dtype).  K3 */
 int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, const float* gamma, const float* beta,
                      void* y, int dtype, float* mean, float* rstd, void* stream);
-/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta accumulate (+=) when accumulate != 0. ws >= 3*768*width floats */
+/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta accumulate (+=) when accumulate != 0. ws >= 3*1024*width floats */
 int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const float* mean, const float* rstd,
                      const float* gamma, int64_t rows, int64_t width, const float* dres, float* dx,
                      void* dx_cast /* optional copy of dx in `dtype`, the next GEMM's operand */,
@@ -133,7 +133,7 @@ int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64
                      int causal, void* stream);
 int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq,
                      int64_t width, int64_t heads, int causal, void* stream);
-/* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 768*n floats */
+/* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 1024*n floats */
 int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate,
               void* ws, size_t ws_bytes, void* stream);
 /* K1: images fp32 [B,3,R,R] -> patches [B*g*g, kpad] (dtype), g = R/P, column (c,ky,kx); columns >= 3*P*P zero */

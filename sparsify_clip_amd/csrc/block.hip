@@ -55,9 +55,9 @@ int check_desc(const sc_block_desc* d, const char* who) {
 
 extern "C" size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype) {
     if (rows <= 0 || width <= 0 || mlp_width <= 0) return 0;
-    size_t need = (size_t)768 * 3 * (size_t)width * sizeof(float);                       // LayerNorm partials
+    size_t need = (size_t)1024 * 3 * (size_t)width * sizeof(float);                       // LayerNorm partials
     const size_t widest = (size_t)(mlp_width > 3 * width ? mlp_width : 3 * width);
-    need = need > 768 * widest * sizeof(float) ? need : 768 * widest * sizeof(float);   // column-sum partials
+    need = need > 1024 * widest * sizeof(float) ? need : 1024 * widest * sizeof(float);   // column-sum partials
     if (dtype == SC_BF16) {
         const int64_t shapes[4][2] = {{3 * width, width}, {width, width}, {mlp_width, width}, {width, mlp_width}};
         for (auto& s : shapes) {

@@ -353,6 +353,95 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 256x128x32, 2 workgroups/CU
+// Same 256x128 tile and wave layout as the kernel above but K-step 32 and three 24-KiB stages (72 KiB): TWO workgroups fit a
+// CU (16 waves, <= 128 VGPRs), so one workgroup's prologue / epilogue (bias, GELU, residual, stores) runs under the other
+// one's MFMAs - the 144-KiB variant leaves the CU idle there.  64-byte LDS rows: chunk c of row r sits at slot
+// c ^ ((-(r >> 2)) & 3), which makes every ds_read_b128 lane group hit 16 distinct 16-B slots (conflict-free).
+constexpr int V3_KSTEP = 32, V3_STAGE = (T_M + T_N) * 64, V3_A = T_M * 64;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_nt_v3_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * V3_STAGE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int band = tile / (GROUP_M * p.tiles_n), r_band = tile - band * (GROUP_M * p.tiles_n);
+    const int rows = min(GROUP_M, p.tiles_m - band * GROUP_M);
+    const int cell = r_band / (rows * GROUP_N), r_cell = r_band - cell * (rows * GROUP_N);
+    const int gw = min(GROUP_N, p.tiles_n - cell * GROUP_N);
+    const int m0 = (band * GROUP_M + r_cell / gw) * T_M, n0 = (cell * GROUP_N + r_cell % gw) * T_N;
+
+    // staging: one wave instruction = 16 rows x 64 B; lane -> (row l>>2, slot l&3) holds chunk slot ^ f(row)
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
+    const bf16_t* ga0 = p.A + (int64_t)min(m0 + wave * 32 + srow, p.M - 1) * p.lda + schunk * 8;
+    const bf16_t* ga1 = p.A + (int64_t)min(m0 + wave * 32 + 16 + srow, p.M - 1) * p.lda + schunk * 8;
+    const bf16_t* gb0 = p.B + (int64_t)min(n0 + wave * 16 + srow, p.N - 1) * p.ldb + schunk * 8;
+#define V3_STAGE_LOAD(S, KT)                                                                          \
+    do {                                                                                              \
+        char* ab__ = smem + (S) * V3_STAGE + (wave * 32) * 64;                                        \
+        glds16(ga0 + (KT) * V3_KSTEP, ab__);                                                          \
+        glds16(ga1 + (KT) * V3_KSTEP, ab__ + 16 * 64);                                                \
+        glds16(gb0 + (KT) * V3_KSTEP, smem + (S) * V3_STAGE + V3_A + (wave * 16) * 64);               \
+    } while (0)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / V3_KSTEP;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fpos = (fq ^ ((-(frow >> 2)) & 3)) * 16;
+    const int a_off = (wm * 64 + frow) * 64 + fpos, b_off = V3_A + (wn * 64 + frow) * 64 + fpos;
+#define V3_BODY(S, KT)                                                                                \
+    do {                                                                                              \
+        if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                           \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) V3_STAGE_LOAD(((S) + 2) % STAGES, (KT) + 2);                               \
+        const char* st__ = smem + (S) * V3_STAGE;                                                     \
+        bf16x8 af__[4], bf__[4];                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) af__[i] = *(const bf16x8*)(st__ + a_off + i * 16 * 64); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) bf__[i] = *(const bf16x8*)(st__ + b_off + i * 16 * 64); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf__[j], af__[i], acc[i][j], 0, 0, 0); \
+    } while (0)
+
+    V3_STAGE_LOAD(0, 0);
+    if (nk > 1) V3_STAGE_LOAD(1, 1);
+    for (int kt = 0; kt < nk; kt += STAGES) {
+        V3_BODY(0, kt);
+        if (kt + 1 < nk) V3_BODY(1, kt + 1);
+        if (kt + 2 < nk) V3_BODY(2, kt + 2);
+    }
+#undef V3_BODY
+#undef V3_STAGE_LOAD
+
+    // D[n][m]: lane holds m = ..+(lane&15), n = ..+4*(lane>>4)+reg : 8-byte (bf16) / 16-byte (fp32) pieces
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+            if (n >= p.N) continue;
+            if (OUT_F32) {
+                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                *(f32x4*)cp = epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, cp);
+            } else {
+                bf16_t* cp = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
+                io<bf16_t>::st4(cp, epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, nullptr));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 // LDS tile: [64 r][128 cols] bf16, 256-B rows.  32-B slot swizzle so that the 8 rows a 32-lane half touches in one
 // ds_read_b64_tr_b16 fall on 8 different 32-B slots of the 256-B bank row.
@@ -693,8 +782,14 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     } else {
         p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
         const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
-        if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
+        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : 2; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant
+        if (variant == 3) {
+            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
+        } else {
+            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
+        }
     }
     SC_CHECK_LAUNCH();
     return SC_OK;

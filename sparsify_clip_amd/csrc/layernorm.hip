@@ -7,24 +7,24 @@
 namespace {
 
 constexpr int LN_MAX_CHUNKS = 8;     // width <= 2048
-constexpr int RED_MAX_BLOCKS = 768;  // partial slabs of the column reductions (3 workgroups per CU)
+constexpr int RED_MAX_BLOCKS = 1024; // partial slabs of the column reductions (4 workgroups per CU)
 constexpr float LN_EPS = 1e-5f;
 
 // RPW rows per wave: all loads of the wave's rows are issued before the first reduction (memory-level parallelism)
-template <typename T, int RPW>
+template <typename T, int RPW, int CH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int64_t rows, int width, const float* gamma, const float* beta,
                                                             T* y, float* mean_out, float* rstd_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
-    f32x4 v[RPW][LN_MAX_CHUNKS];
+    f32x4 v[RPW][CH];
     float s[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         s[r] = 0.f;
         const int64_t row = min(row0 + r, rows - 1);
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const int idx = c * 256 + lane * 4;
             if (idx < width) {
                 v[r][c] = *(const f32x4*)(x + row * width + idx);
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int6
         const float mean = wave_sum(s[r]) / (float)width;
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const int idx = c * 256 + lane * 4;
             if (idx < width) {
 #pragma unroll
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int6
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + LN_EPS);
         if (row >= rows) continue;
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const int idx = c * 256 + lane * 4;
             if (idx < width) {
                 const f32x4 g = *(const f32x4*)(gamma + idx), b = *(const f32x4*)(beta + idx);
@@ -70,21 +70,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int6
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
 // partial[block][0][w] = sum_rows dy*xhat ; partial[block][1][w] = sum_rows dy ; partial[block][2][w] = sum_rows dx (NSUM == 3)
-template <typename T, int NSUM>
+template <typename T, int NSUM, int CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                                             int64_t rows, int width, const float* dres, float* dx, T* dx_cast, float* partial) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [wave][which][width]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    f32x4 ag[LN_MAX_CHUNKS], ab[LN_MAX_CHUNKS], ad[LN_MAX_CHUNKS];
+    f32x4 ag[CH], ab[CH], ad[CH];
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) ag[c] = ab[c] = ad[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < CH; ++c) ag[c] = ab[c] = ad[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float invw = 1.0f / (float)width;
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[LN_MAX_CHUNKS], g[LN_MAX_CHUNKS];
+        f32x4 xh[CH], g[CH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const int idx = c * 256 + lane * 4;
             if (idx < width) {
                 const f32x4 xv = *(const f32x4*)(x + row * width + idx);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
         s1 = wave_sum(s1) * invw;
         s2 = wave_sum(s2) * invw;
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const int idx = c * 256 + lane * 4;
             if (idx < width) {
                 f32x4 o;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
         }
     }
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const int idx = c * 256 + lane * 4;
         if (idx < width) {
             *(f32x4*)&red[(w * NSUM + 0) * width + idx] = ag[c];
@@ -179,19 +179,18 @@ extern "C" int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, con
     SC_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && width <= LN_MAX_CHUNKS * 256, SC_ERR_SHAPE,
                "sc_layernorm_fwd: width %lld must be a multiple of 4 and <= %d", (long long)width, LN_MAX_CHUNKS * 256);
     SC_REQUIRE(sc_aligned(x, 16) && sc_aligned(y, 8) && sc_aligned(gamma, 16) && sc_aligned(beta, 16), SC_ERR_ALIGN, "sc_layernorm_fwd: misaligned");
-    // narrow rows: 4 rows per wave keep enough bytes in flight; wide rows already fill the registers
-    const bool multi = width <= 1024;
+    // the chunk count (256 columns per chunk) is a compile-time parameter: registers, and with them the waves in flight,
+    // follow the actual width instead of the 2048-column maximum; narrow rows take 4 rows per wave
+    const int ch = width <= 512 ? 2 : width <= 768 ? 3 : width <= 1024 ? 4 : 8;
+    const bool multi = ch <= 4;
     const dim3 grid((unsigned)sc_cdiv(rows, multi ? 16 : 4));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SC_BF16) {
-        if (multi) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (bf16_t*)y, mean, rstd);
-        else hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (bf16_t*)y, mean, rstd);
-    } else if (dtype == SC_F32) {
-        if (multi) hipLaunchKernelGGL((layernorm_fwd_kernel<float, 4>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (float*)y, mean, rstd);
-        else hipLaunchKernelGGL((layernorm_fwd_kernel<float, 1>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (float*)y, mean, rstd);
-    }
-    else
-        return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_fwd: bad dtype %d", dtype);
+    if (dtype != SC_BF16 && dtype != SC_F32) return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_fwd: bad dtype %d", dtype);
+#define LN_FWD(T, R, C) hipLaunchKernelGGL((layernorm_fwd_kernel<T, R, C>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (T*)y, mean, rstd)
+#define LN_FWD_T(T) do { if (ch == 2) LN_FWD(T, 4, 2); else if (ch == 3) LN_FWD(T, 4, 3); else if (ch == 4) LN_FWD(T, 4, 4); else LN_FWD(T, 1, 8); } while (0)
+    if (dtype == SC_BF16) LN_FWD_T(bf16_t); else LN_FWD_T(float);
+#undef LN_FWD_T
+#undef LN_FWD
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
@@ -207,10 +206,13 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
     SC_REQUIRE(sc_aligned(ws, 16) && sc_aligned(x, 16) && sc_aligned(dx, 16) && sc_aligned(dy, 8), SC_ERR_ALIGN, "sc_layernorm_bwd: misaligned");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = (size_t)4 * nsum * width * sizeof(float);
-#define LN_BWD(T, NS) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NS>), dim3(nblocks), dim3(256), lds_bytes, st, (const T*)dy, x, mean, rstd, gamma, rows, (int)width, dres, dx, (T*)dx_cast, (float*)ws)
-    if (dtype == SC_BF16) { if (nsum == 3) LN_BWD(bf16_t, 3); else LN_BWD(bf16_t, 2); }
-    else if (dtype == SC_F32) { if (nsum == 3) LN_BWD(float, 3); else LN_BWD(float, 2); }
-    else return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_bwd: bad dtype %d", dtype);
+    const int ch = width <= 512 ? 2 : width <= 768 ? 3 : width <= 1024 ? 4 : 8;
+    if (dtype != SC_BF16 && dtype != SC_F32) return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_bwd: bad dtype %d", dtype);
+#define LN_BWD(T, NS, C) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NS, C>), dim3(nblocks), dim3(256), lds_bytes, st, (const T*)dy, x, mean, rstd, gamma, rows, (int)width, dres, dx, (T*)dx_cast, (float*)ws)
+#define LN_BWD_C(T, NS) do { if (ch == 2) LN_BWD(T, NS, 2); else if (ch == 3) LN_BWD(T, NS, 3); else if (ch == 4) LN_BWD(T, NS, 4); else LN_BWD(T, NS, 8); } while (0)
+    if (dtype == SC_BF16) { if (nsum == 3) LN_BWD_C(bf16_t, 3); else LN_BWD_C(bf16_t, 2); }
+    else { if (nsum == 3) LN_BWD_C(float, 3); else LN_BWD_C(float, 2); }
+#undef LN_BWD_C
 #undef LN_BWD
     if (dgamma || dbeta || dx_colsum)
         hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 16)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,

@@ -186,7 +186,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_cast=False, dgamma=N
     if dgamma is None:
         dgamma = torch.zeros(w, dtype=torch.float32, device=x.device)
         dbeta = torch.zeros(w, dtype=torch.float32, device=x.device)
-    ws = _workspace(768 * 3 * w * 4, x.device)
+    ws = _workspace(1024 * 3 * w * 4, x.device)
     LIB.call("sc_layernorm_bwd", ptr(dy), sc_dtype(dy.dtype), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), rows, w, ptr(dres), ptr(dx), ptr(dx_cast),
              ptr(dgamma), ptr(dbeta), ptr(dx_colsum), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
     return dx, dx_cast, dgamma, dbeta
@@ -211,7 +211,7 @@ def colsum(x, out=None, accumulate=False):
     rows, n = x.shape
     if out is None:
         out = torch.zeros(n, dtype=torch.float32, device=x.device)
-    ws = _workspace(768 * n * 4, x.device)
+    ws = _workspace(1024 * n * 4, x.device)
     LIB.call("sc_colsum", ptr(x), sc_dtype(x.dtype), rows, n, n, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
     return out
 
