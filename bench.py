@@ -180,7 +180,7 @@ def main():
     out = {"metric": "image-text pairs/sec", "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-           "config": {"workload": f"{os.path.basename(key)} main phase (anchor+lalign+lunif(centroids)), {args.model}, local batch {args.local_batch}/GPU, "
+           "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, local batch {args.local_batch}/GPU, "
                                   f"global batch {global_batch}, AdamW, random-init weights",
                       "global_batch": global_batch, "local_batch": args.local_batch, "parallelism": f"dp{world}"},
            "last_loss": last_loss,

@@ -263,3 +263,28 @@ def test_full_size_step_properties_bf16(pkg):
     assert torch.equal(runs[0][1], runs[1][1])
     assert all(np.isfinite(l) for l in runs[0][0]) and torch.isfinite(runs[0][1]).all()
     assert runs[0][0][0] != runs[0][0][2]          # the optimiser moved the model (step 1 runs at lr 0)
+
+
+def test_c5_vit_l14_step_runs_bf16(pkg):
+    """BASELINE config #5's model and loss stack (experiment_10: anchor + ALPHA*lalign + BETA*lunif(centroids) on ViT-L/14) at a
+    small batch: two bf16 training steps run end to end (K = 588 patch GEMM padded to 640, S = 257 block-per-head attention,
+    width-1024 LayerNorm), stay finite, move the parameters, and repeat bit-identically."""
+    from conftest import load_json
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.data import synthetic_batch
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if "experiment_10-" in k][0]]
+    cfg = finalize_config(raw, 0, {"model": "ViT-L-14", "batch_size": 16, "precision": "bf16"})
+    images, tokens = [t.to(DEV) for t in synthetic_batch(7, 16)]
+    outs = []
+    for _ in range(2):
+        tr = Trainer(cfg, DEV, 100)
+        tr.current_batch = 60          # inside the alpha ramp / beta decay of a 10000-step run
+        losses = [tr.step(images, tokens).item() for _ in range(2)]
+        outs.append((losses, tr.beta, tr.alpha, tr.model.param("visual.proj").clone()))
+        del tr
+        torch.cuda.empty_cache()
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][3], outs[1][3])
+    assert all(np.isfinite(l) for l in outs[0][0])
+    assert 0.0 < outs[0][1] <= 1.0 and 1.0 <= outs[0][2] <= 2.0
