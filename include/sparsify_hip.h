@@ -72,6 +72,12 @@ int sc_gemm_bf16_nt(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda,
 size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t r);
 int sc_gemm_bf16_tn(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb,
                     float* c, int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, void* stream);
+/* Same, plus colsum_a[m] = colsum_beta * colsum_a[m] + sum_r A[r][m] from the same staged tiles: with A = dY this is the
+ * bias gradient of the linear layer whose weight gradient the call computes (autograd of nn.Linear under reference
+ * sparsify_clip.py:965 loss.backward()).  colsum_a: M fp32, 16-byte aligned. */
+int sc_gemm_bf16_tn_colsum(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb,
+                           float* c, int64_t ldc, float alpha, float beta, float* colsum_a, float colsum_beta,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss head on [B,E] fp32 embeddings  (sparsify_clip.py:110-187, :334-355, :772-773, :804)

@@ -13,7 +13,7 @@ int sc_gemm_f32_launch(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k
 int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc,
                            int out_dtype, const EpiParams& epi, hipStream_t stream);
 int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
-                           float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream);
+                           float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta);
 size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r);
 
 namespace {
@@ -30,11 +30,13 @@ int linear_dx(int dtype, int64_t rows, int64_t n, int64_t k, const void* dy, con
     if (dtype == SC_BF16) return sc_gemm_bf16_nt_launch(rows, k, n, dy, n, wt, n, dx, k, SC_BF16, epi, st);
     return sc_gemm_f32_launch(0, 0, rows, k, n, (const float*)dy, n, (const float*)w, k, (float*)dx, k, epi, st);
 }
-// dw[n,k] (+)= dy[rows,n]^T x[rows,k]
+// dw[n,k] (+)= dy[rows,n]^T x[rows,k]; bf16 with db != null: db[n] (+)= column sums of dy, fused into the same kernel (the
+// weight-gradient GEMM stages every dy tile in LDS anyway, so the bias gradient costs no extra pass over dy)
 int linear_dw(int dtype, int64_t rows, int64_t n, int64_t k, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes,
-              hipStream_t st) {
-    if (dtype == SC_BF16) return sc_gemm_bf16_tn_launch(n, k, rows, dy, n, x, k, dw, k, 1.f, accumulate ? 1.f : 0.f, ws, ws_bytes, st);
-    return sc_gemm_f32_launch(1, 0, n, k, rows, (const float*)dy, n, (const float*)x, k, dw, k, epi_plain(1.f, accumulate ? 1.f : 0.f), st);
+              hipStream_t st, float* db = nullptr) {
+    const float beta = accumulate ? 1.f : 0.f;
+    if (dtype == SC_BF16) return sc_gemm_bf16_tn_launch(n, k, rows, dy, n, x, k, dw, k, 1.f, beta, ws, ws_bytes, st, db, beta);
+    return sc_gemm_f32_launch(1, 0, n, k, rows, (const float*)dy, n, (const float*)x, k, dw, k, epi_plain(1.f, beta), st);
 }
 
 int check_desc(const sc_block_desc* d, const char* who) {
@@ -152,8 +154,8 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
     SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
-    SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
+    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss, bf ? d->g_b_fc1 : nullptr));
+    if (!bf) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
     // dx_mid = dx_out + LN2'(d_ln); the same kernel emits the operand copy and the out_proj bias gradient (column sums of dx_mid).
     // With a side stream the copy must not land in the buffer `g` that the side stream may still be reading (internal-cast case).
@@ -167,8 +169,8 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
     SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));
-    SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
+    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss, bf ? d->g_b_qkv : nullptr));
+    if (!bf) SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
     // dx_in = dx_mid + LN1'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,

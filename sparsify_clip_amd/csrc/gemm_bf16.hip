@@ -39,6 +39,9 @@ struct GemmBf16Params {
     int tiles_m, tiles_n;
     int splits, k_per_split;   // TN only (k_per_split in units of KSTEP tiles)
     float* partial;            // TN split-R partial slabs [splits][M][N] or null
+    float* cs_out;             // TN: optional column sums of A over r, cs_out[m] = cs_beta * cs_out[m] + sum_r A[r][m]  (bias gradient)
+    float* cs_partial;         // TN: [splits][M] partial column sums when the contraction is split
+    float cs_beta;
     EpiParams epi;
 };
 
@@ -325,15 +328,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
                 io<bf16_t>::st4((bf16_t*)e.pre_out + off + 4, v1);
             }
             if (e.act == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v0[j] = gelu_fast(v0[j]); v1[j] = gelu_fast(v1[j]); }
+                v0 = gelu_fast4(v0); v1 = gelu_fast4(v1);
             }
             if (has_pre) {
                 const uint4 h = hpre[it];
-                v0[0] *= gelu_grad_fast(__uint_as_float(h.x << 16)); v0[1] *= gelu_grad_fast(__uint_as_float(h.x & 0xffff0000u));
-                v0[2] *= gelu_grad_fast(__uint_as_float(h.y << 16)); v0[3] *= gelu_grad_fast(__uint_as_float(h.y & 0xffff0000u));
-                v1[0] *= gelu_grad_fast(__uint_as_float(h.z << 16)); v1[1] *= gelu_grad_fast(__uint_as_float(h.z & 0xffff0000u));
-                v1[2] *= gelu_grad_fast(__uint_as_float(h.w << 16)); v1[3] *= gelu_grad_fast(__uint_as_float(h.w & 0xffff0000u));
+                v0 = gelu_grad_mul4(v0, h.x, h.y); v1 = gelu_grad_mul4(v1, h.z, h.w);
             }
             if (has_res) { v0 += res0[it]; v1 += res1[it]; }
             if (OUT_F32) {
@@ -349,6 +348,210 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
                 u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
                 *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NT, 256x256, 2-stage
+// Twice the B panel per workgroup: 128 flop per LDS-DMA byte instead of 85.  tools/ingest_bench.hip takes the main loop
+// apart on the fc1 shape: with the 256x128 tile, LDS-DMA + fragment reads + MFMAs (no epilogue) run at 1.08 PFLOP/s-equivalent,
+// with this tile and wave layout at 1.33 - the loop is bound by how many operand bytes one CU can keep in flight.
+// 8 waves as 2(M) x 4(N), each wave a 128x64 sub-tile = 8x4 MFMA tiles.  Two LDS stages of (32 KiB A + 32 KiB B), K-step 64,
+// one barrier per K-tile placed between its two 32-MFMA sub-steps.
+// The 128 accumulator registers of a wave are the physical AGPRs a0..a127, named directly in inline assembly: MFMA tile (i, j)
+// lives in a[4(4i+j) : 4(4i+j)+3].  Left to itself hipcc keeps the accumulators of such a loop in VGPRs, runs out of them and
+// shuttles values through v_accvgpr_read/write and scratch around every MFMA.  MFMAs and fragment reads are therefore emitted
+// as inline assembly in their final order: row tile i's four MFMAs, then the read that reloads a[i] for the NEXT sub-step
+// into the same registers (dead by then), the B fragments ping-pong between two sets - 64 fragment VGPRs in all.
+// The compiler never sees the AGPRs, so the kernel must not spill (checked at build time) and the hazards it can no longer
+// see are handled by hand: s_waitcnt lgkmcnt before the first MFMA that consumes a fragment, s_nop before the read-back.
+constexpr int B_M = 256, B_N = 256, B_STAGE = (B_M + B_N) * 128, B_A = B_M * 128, B_GROUP_M = 8, B_GROUP_N = 4, B_LDS = 8 * 64 * 68 * 4;
+
+template <int F>
+__device__ __forceinline__ void ntb_mfma(const bf16x8 (&a)[8], const bf16x8 (&b)[4]) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3));
+}
+template <int OFF>
+__device__ __forceinline__ void ntb_read(bf16x8& dst, unsigned base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(OFF) : "memory");
+}
+// one sub-step: 8 groups of 4 MFMAs; when LOAD, group I is followed by the read of next sub-step's a[I] (in place) and, for
+// I < 4, of its B fragment I into the other B set
+template <int I, bool LOAD>
+__device__ __forceinline__ void ntb_substep(bf16x8 (&a)[8], const bf16x8 (&b)[4], bf16x8 (&bn)[4], unsigned abase, unsigned bbase) {
+    ntb_mfma<4 * I>(a, b); ntb_mfma<4 * I + 1>(a, b); ntb_mfma<4 * I + 2>(a, b); ntb_mfma<4 * I + 3>(a, b);
+    if constexpr (LOAD) {
+        ntb_read<I * 2048>(a[I], abase);
+        if constexpr (I < 4) ntb_read<I * 2048>(bn[I], bbase);
+    }
+    if constexpr (I + 1 < 8) ntb_substep<I + 1, LOAD>(a, b, bn, abase, bbase);
+}
+template <int N>
+__device__ __forceinline__ void ntb_zero() {
+    asm volatile("v_accvgpr_write_b32 a[%0], 0\n v_accvgpr_write_b32 a[%1], 0\n v_accvgpr_write_b32 a[%2], 0\n v_accvgpr_write_b32 a[%3], 0"
+                 : : "n"(N), "n"(N + 1), "n"(N + 2), "n"(N + 3));
+    if constexpr (N + 4 < 128) ntb_zero<N + 4>();
+}
+template <int T>
+__device__ __forceinline__ f32x4 ntb_acc() {   // accumulator tile T = 4 i + j
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n v_accvgpr_read_b32 %1, a[%5]\n v_accvgpr_read_b32 %2, a[%6]\n v_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3));
+    return v;
+}
+template <int T, int H>
+__device__ __forceinline__ void ntb_to_slab(float* slab_lane) {   // rows 64 H .. 64 H + 63 of the wave's sub-tile: i = 4 H + T / 4, j = T % 4
+    *(f32x4*)(slab_lane + (16 * (T / 4)) * 68 + 16 * (T % 4)) = ntb_acc<16 * H + T>();
+    if constexpr (T + 1 < 16) ntb_to_slab<T + 1, H>(slab_lane);
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[B_LDS];   // 139264 >= 2 stages (131072); eight 64x68-float epilogue slabs
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int band = tile / (B_GROUP_M * p.tiles_n), r_band = tile - band * (B_GROUP_M * p.tiles_n);
+    const int rows = min(B_GROUP_M, p.tiles_m - band * B_GROUP_M);
+    const int cell = r_band / (rows * B_GROUP_N), r_cell = r_band - cell * (rows * B_GROUP_N);
+    const int gw = min(B_GROUP_N, p.tiles_n - cell * B_GROUP_N);
+    const int m0 = (band * B_GROUP_M + r_cell / gw) * B_M, n0 = (cell * B_GROUP_N + r_cell % gw) * B_N;
+
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ga[q] = p.A + (int64_t)min(m0 + wave * 32 + q * 8 + srow, p.M - 1) * p.lda + schunk * 8;
+        gb[q] = p.B + (int64_t)min(n0 + wave * 32 + q * 8 + srow, p.N - 1) * p.ldb + schunk * 8;
+    }
+    // reserves a0..a127 in the kernel descriptor (the compiler allocates what it sees clobbered) and clears them
+    asm volatile("" ::: "a0", "a127");
+    ntb_zero<0>();
+
+    const int nk = p.K / KSTEP;
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned pos0 = ((fq) ^ (lane & 7)) * 16, pos1 = ((4 + fq) ^ (lane & 7)) * 16;
+    const unsigned fa = lds0 + (wm * 128 + frow) * 128, fb = lds0 + B_A + (wn * 64 + frow) * 128;
+    // fragment i of stage S, sub-step s: base[S][s] + i * 2048 (the DS offset field holds 16 bits, so each stage has its own base)
+    const unsigned fa00 = fa + pos0, fa01 = fa + pos1, fa10 = fa + B_STAGE + pos0, fa11 = fa + B_STAGE + pos1;
+    const unsigned fb00 = fb + pos0, fb01 = fb + pos1, fb10 = fb + B_STAGE + pos0, fb11 = fb + B_STAGE + pos1;
+
+#define NTB_STAGE(S, KT)                                                                              \
+    do {                                                                                              \
+        char* ab__ = smem + (S) * B_STAGE + (wave * 32) * 128;                                        \
+        char* bb__ = ab__ + B_A;                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(ga[q] + (KT) * KSTEP, ab__ + q * 8 * 128); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(gb[q] + (KT) * KSTEP, bb__ + q * 8 * 128); \
+    } while (0)
+    // Stage S holds tile KT.  Sub-step 0 of tile KT runs while the fragments of its sub-step 1 are read (stage S); the barrier
+    // publishes tile KT+1 (vmcnt(0): the only tile in flight) and retires every read of stage S (lgkmcnt(0)), so the LDS-DMA
+    // of tile KT+2 may overwrite stage S right behind it; sub-step 1 then reads the first fragments of tile KT+1 from S^1.
+#define NTB_BODY(S, KT, A_S1, B_S1, A_N0, B_N0)                                                       \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        ntb_substep<0, true>(a, b0, b1, A_S1, B_S1);                                                  \
+        if ((KT) + 1 < nk) {                                                                          \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                               \
+            __builtin_amdgcn_s_barrier();                                                             \
+            if ((KT) + 2 < nk) NTB_STAGE(S, (KT) + 2);                                                \
+            ntb_substep<0, true>(a, b1, b0, A_N0, B_N0);                                              \
+        } else {                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+            ntb_substep<0, false>(a, b1, b0, A_N0, B_N0);                                             \
+        }                                                                                             \
+    } while (0)
+
+    bf16x8 a[8], b0[4], b1[4];
+    NTB_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) NTB_STAGE(1, 1);
+    ntb_read<0>(b0[0], fb00); ntb_read<2048>(b0[1], fb00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(b0[3], fb00);
+    ntb_read<0>(a[0], fa00); ntb_read<2048>(a[1], fa00); ntb_read<4096>(a[2], fa00); ntb_read<6144>(a[3], fa00);
+    ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
+    for (int kt = 0; kt < nk; kt += 2) {
+        NTB_BODY(0, kt, fa01, fb01, fa10, fb10);
+        if (kt + 1 < nk) NTB_BODY(1, kt + 1, fa11, fb11, fa00, fb00);
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
+#undef NTB_BODY
+#undef NTB_STAGE
+
+    // Epilogue: as in the 256x128 kernel (per-wave 64x64 LDS slab, row-major 16-byte pieces), two passes of 64 rows per wave.
+    const EpiParams& e = p.epi;
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + ecol;
+    const bool ncol_ok = n < p.N;
+    const int nn = ncol_ok ? n : 0;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    const bool has_pre = e.dgelu_pre != nullptr, has_res = e.resid != nullptr, res_f32 = e.resid_dtype == SC_F32;
+    if (e.bias) { bias0 = *(const f32x4*)(e.bias + nn); bias1 = *(const f32x4*)(e.bias + nn + 4); }
+    __syncthreads();   // every wave is done reading the last K-tile
+    float* slab = (float*)smem + wave * (64 * 68);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int mw = m0 + wm * 128 + h * 64;
+        if (h == 0) ntb_to_slab<0, 0>(slab + frow * 68 + 4 * fq);
+        else ntb_to_slab<0, 1>(slab + frow * 68 + 4 * fq);
+        if (ncol_ok) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {   // 4 rows per lane at a time: their GELU' / residual operands are requested together
+            uint4 hpre[4];
+            f32x4 res0[4], res1[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = min(mw + (4 * g + it) * 8 + erow, p.M - 1);
+                const int64_t off = (int64_t)m * e.ld_aux + nn;
+                if (has_pre) hpre[it] = *(const uint4*)((const bf16_t*)e.dgelu_pre + off);
+                if (has_res) {
+                    if (res_f32) {
+                        res0[it] = *(const f32x4*)((const float*)e.resid + off);
+                        res1[it] = *(const f32x4*)((const float*)e.resid + off + 4);
+                    } else {
+                        res0[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off);
+                        res1[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = (4 * g + it) * 8 + erow;
+                const int m = mw + row;
+                if (m >= p.M) continue;
+                f32x4 v0 = *(const f32x4*)(slab + row * 68 + ecol) * e.alpha + bias0;
+                f32x4 v1 = *(const f32x4*)(slab + row * 68 + ecol + 4) * e.alpha + bias1;
+                const int64_t off = (int64_t)m * e.ld_aux + n;
+                if (e.pre_out) {
+                    io<bf16_t>::st4((bf16_t*)e.pre_out + off, v0);
+                    io<bf16_t>::st4((bf16_t*)e.pre_out + off + 4, v1);
+                }
+                if (e.act == 1) {
+                    v0 = gelu_fast4(v0); v1 = gelu_fast4(v1);
+                }
+                if (has_pre) {
+                    const uint4 hh = hpre[it];
+                    v0 = gelu_grad_mul4(v0, hh.x, hh.y); v1 = gelu_grad_mul4(v1, hh.z, hh.w);
+                }
+                if (has_res) { v0 += res0[it]; v1 += res1[it]; }
+                if (OUT_F32) {
+                    float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                    if (e.beta != 0.f) { v0 += *(const f32x4*)cp * e.beta; v1 += *(const f32x4*)(cp + 4) * e.beta; }
+                    *(f32x4*)cp = v0;
+                    *(f32x4*)(cp + 4) = v1;
+                } else {
+                    uint4 u;
+                    u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
+                    u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
+                    u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
+                    u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+                    *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
+                }
+            }
+          }
         }
     }
 }
@@ -498,6 +701,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Fused bias gradient: the workgroups of the first tile column also sum their staged A tiles over r.  Thread t owns the 8
+    // columns of chunk t & 15 and the 4 rows 4 (t >> 4) .. +3 of every K-tile (one ds_read_b128 per row, the staging swizzle undone).
+    const bool do_cs = p.cs_out != nullptr && n0 == 0;
+    const int cs_cg = t & 15, cs_rg = t >> 4;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     if (kt_begin < kt_end) {
         stage(0, kt_begin);
@@ -511,6 +719,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
         const int cur = (kt - kt_begin) & 1;
         const char* abase = smem + cur * BUF_BYTES;
         const char* bbase = abase + OPER_BYTES;
+        if (do_cs) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = cs_rg * 4 + q;
+                const uint4 v = *(const uint4*)(abase + row * 256 + ((cs_cg ^ tn_swz(row)) << 4));
+                cs[0] += __uint_as_float(v.x << 16); cs[1] += __uint_as_float(v.x & 0xffff0000u);
+                cs[2] += __uint_as_float(v.y << 16); cs[3] += __uint_as_float(v.y & 0xffff0000u);
+                cs[4] += __uint_as_float(v.z << 16); cs[5] += __uint_as_float(v.z & 0xffff0000u);
+                cs[6] += __uint_as_float(v.w << 16); cs[7] += __uint_as_float(v.w & 0xffff0000u);
+            }
+        }
         bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -563,6 +782,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
                 if (p.epi.beta != 0.f) v += *(const f32x4*)cp * p.epi.beta;
                 *(f32x4*)cp = v;
             }
+        }
+    }
+    if (do_cs) {   // fixed-order reduction: 4 row groups per wave (lane bits 4, 5), then the 4 waves through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64);
+        }
+        float* red = (float*)smem;   // the K loop ended on a barrier: the operand tiles are dead
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave * 128 + lane * 8 + e] = cs[e];
+        }
+        __syncthreads();
+        const int m = m0 + t;
+        if (t < 128 && m < p.M) {
+            const float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+            if (p.cs_partial) p.cs_partial[(int64_t)split * p.M + m] = v;
+            else p.cs_out[m] = p.cs_beta != 0.f ? v + p.cs_beta * p.cs_out[m] : v;
         }
     }
 }
@@ -719,9 +957,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(GemmBf16Params 
     }
 }
 
-// C = alpha * sum_s partial[s] + beta * C   (fixed order)
+// C = alpha * sum_s partial[s] + beta * C   (fixed order); optionally also cs_out = cs_beta * cs_out + sum_s cs_partial[s]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, int64_t mn, int n, float* c, int64_t ldc,
-                                                            float alpha, float beta) {
+                                                            float alpha, float beta, const float* cs_partial, float* cs_out, int m_len, float cs_beta) {
     const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= mn) return;
     f32x4 s = *(const f32x4*)(partial + i4);
@@ -730,6 +968,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
     f32x4 v = s * alpha;
     if (beta != 0.f) v += *(const f32x4*)cp * beta;
     *(f32x4*)cp = v;
+    if (cs_partial && i4 < m_len) {
+        f32x4 b = *(const f32x4*)(cs_partial + i4);
+        for (int k = 1; k < splits; ++k) b += *(const f32x4*)(cs_partial + (int64_t)k * m_len + i4);
+        if (cs_beta != 0.f) b += *(const f32x4*)(cs_out + i4) * cs_beta;
+        *(f32x4*)(cs_out + i4) = b;
+    }
 }
 
 bool tn_small() {
@@ -782,8 +1026,13 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     } else {
         p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
         const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
-        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : 2; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant
-        if (variant == 3) {
+        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : (e && e[0] == '2') ? 2 : 0; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant, =2: 256x128 everywhere
+        if (variant == 0 && n >= 1536 && m >= 4096) {
+            p.tiles_m = (int)sc_cdiv(m, B_M); p.tiles_n = (int)sc_cdiv(n, B_N);
+            const unsigned gridb = (unsigned)(p.tiles_m * p.tiles_n);
+            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
+        } else if (variant == 3) {
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
         } else {
@@ -797,11 +1046,11 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
 
 size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r) {
     const int s = tn_splits(m, n, r);
-    return s > 1 ? (size_t)s * m * n * sizeof(float) : 0;
+    return s > 1 ? (size_t)s * (m * n + m) * sizeof(float) : 0;   // partial C slabs + partial column sums of A
 }
 
 int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c,
-                           int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream) {
+                           int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta) {
     SC_REQUIRE(m > 0 && n > 0 && r > 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn: empty problem");
     SC_REQUIRE(a && b && c, SC_ERR_ARG, "sc_gemm_bf16_tn: null operand");
     SC_REQUIRE(m % 8 == 0 && n % 8 == 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn: M and N must be multiples of 8");
@@ -811,18 +1060,21 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)r;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    const bool small = tn_small();
+    SC_REQUIRE(!colsum_a || sc_aligned(colsum_a, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: colsum must be 16-byte aligned");
+    const bool small = tn_small() || colsum_a != nullptr;   // the fused column sums live in the 128x128 kernel
     p.tiles_m = (int)sc_cdiv(m, small ? TILE : T_M); p.tiles_n = (int)sc_cdiv(n, small ? TILE : T_N);
     p.splits = tn_splits(m, n, r);
+    p.cs_out = colsum_a; p.cs_partial = nullptr; p.cs_beta = colsum_beta;
     const int64_t nk = sc_cdiv(r, KSTEP);
     p.k_per_split = (int)sc_cdiv(nk, p.splits);
     p.splits = (int)sc_cdiv(nk, p.k_per_split);
     p.partial = nullptr;
     p.epi = epi_plain(alpha, beta);
     if (p.splits > 1) {
-        SC_REQUIRE(ws && ws_bytes >= (size_t)p.splits * m * n * sizeof(float), SC_ERR_WORKSPACE, "sc_gemm_bf16_tn: workspace too small");
+        SC_REQUIRE(ws && ws_bytes >= (size_t)p.splits * (m * n + m) * sizeof(float), SC_ERR_WORKSPACE, "sc_gemm_bf16_tn: workspace too small");
         SC_REQUIRE(sc_aligned(ws, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: workspace must be 16-byte aligned");
         p.partial = (float*)ws;
+        if (colsum_a) p.cs_partial = (float*)ws + (size_t)p.splits * m * n;
     }
     const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n * p.splits);
     if (small) hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
@@ -831,7 +1083,7 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     if (p.splits > 1) {
         const int64_t mn = m * n;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)sc_cdiv(mn / 4, 256)), dim3(256), 0, stream, p.partial, p.splits, mn, (int)n, c, ldc,
-                           alpha, beta);
+                           alpha, beta, p.cs_partial, colsum_a, (int)m, colsum_beta);
         SC_CHECK_LAUNCH();
     }
     return SC_OK;
@@ -849,5 +1101,10 @@ extern "C" size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t 
 }
 extern "C" int sc_gemm_bf16_tn(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
                                float alpha, float beta, void* ws, size_t ws_bytes, void* stream) {
-    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream);
+    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream, nullptr, 0.f);
+}
+extern "C" int sc_gemm_bf16_tn_colsum(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
+                                      float alpha, float beta, float* colsum_a, float colsum_beta, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(colsum_a != nullptr, SC_ERR_ARG, "sc_gemm_bf16_tn_colsum: null colsum_a");
+    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream, colsum_a, colsum_beta);
 }

@@ -60,7 +60,7 @@ __device__ __forceinline__ f32x4 epi_vec4(const EpiParams& e, f32x4 acc, int m, 
     if (e.bias) v += *(const f32x4*)(e.bias + n);
     const int64_t off = (int64_t)m * e.ld_aux + n;
     if (e.pre_out) io<TAux>::st4((TAux*)e.pre_out + off, v);
-    constexpr bool FAST = sizeof(TAux) == 2;   // bf16 activations: the 1.5e-7 erf approximation is exact at bf16 resolution
+    constexpr bool FAST = sizeof(TAux) == 2;   // bf16 activations: the 1e-5 polynomial forms (common.h) are exact at bf16 resolution
     if (e.act == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = FAST ? gelu_fast(v[j]) : gelu_f(v[j]);

@@ -63,8 +63,9 @@ def gemm_bf16_nt(a, b, out_dtype=torch.bfloat16, out=None, epi: GemmEpilogue | N
     return out
 
 
-def gemm_bf16_tn(a, b, out=None, alpha=1.0, beta=0.0):
-    """out[M,N] = alpha * a[R,M]^T b[R,N] + beta*out (fp32)."""
+def gemm_bf16_tn(a, b, out=None, alpha=1.0, beta=0.0, colsum_out=None, colsum_beta=0.0):
+    """out[M,N] = alpha * a[R,M]^T b[R,N] + beta*out (fp32); with colsum_out ([M] fp32) also
+    colsum_out = colsum_beta * colsum_out + a.sum(0) from the same kernel (the bias gradient when a = dY)."""
     require_gpu(a, "a", torch.bfloat16), require_gpu(b, "b", torch.bfloat16)
     r, m = a.shape
     n = b.shape[1]
@@ -72,7 +73,14 @@ def gemm_bf16_tn(a, b, out=None, alpha=1.0, beta=0.0):
         out = torch.zeros(m, n, dtype=torch.float32, device=a.device)
     nbytes = LIB.raw("sc_gemm_bf16_tn_workspace_bytes")(m, n, r)
     ws = _workspace(nbytes, a.device)
-    LIB.call("sc_gemm_bf16_tn", m, n, r, ptr(a), m, ptr(b), n, ptr(out), n, float(alpha), float(beta), ptr(ws), ws.numel(), stream_ptr())
+    if colsum_out is None:
+        LIB.call("sc_gemm_bf16_tn", m, n, r, ptr(a), m, ptr(b), n, ptr(out), n, float(alpha), float(beta), ptr(ws), ws.numel(), stream_ptr())
+        return out
+    require_gpu(colsum_out, "colsum_out", torch.float32)
+    if colsum_out.numel() != m:
+        raise ScError(f"gemm_bf16_tn: colsum_out has {colsum_out.numel()} elements, expected {m}")
+    LIB.call("sc_gemm_bf16_tn_colsum", m, n, r, ptr(a), m, ptr(b), n, ptr(out), n, float(alpha), float(beta), ptr(colsum_out), float(colsum_beta),
+             ptr(ws), ws.numel(), stream_ptr())
     return out
 
 

@@ -89,6 +89,45 @@ def test_gemm_bf16_nt(ops, m, n, k, out_dtype):
     assert_close(got, want, rt, 2e-3 * np.sqrt(k), f"gemm_bf16_nt {m}x{n}x{k}")
 
 
+@pytest.mark.parametrize("m,n,k", [(4096, 1536, 64), (4100, 1544, 192), (4352, 2304, 768), (5000, 1800, 128)])
+def test_gemm_bf16_nt_wide(ops, m, n, k):
+    """Shapes that dispatch to the 256x256 four-wave kernel (M >= 4096, N >= 1536): full and ragged tiles, odd / even K-tile
+    counts, every epilogue, checked element by element against fp64 on the same bf16 operands (computed on the device)."""
+    a, w = rnd(m, k, seed=21, dtype=torch.bfloat16).to(DEV), rnd(n, k, seed=22, scale=0.1, dtype=torch.bfloat16).to(DEV)
+    bias, resid = rnd(n, seed=23).to(DEV), rnd(m, n, seed=24).to(DEV)
+    acc = a.double() @ w.double().t()
+    got = ops.gemm_bf16_nt(a, w, out_dtype=torch.float32)
+    assert_close(got, acc, 1e-4, 2e-3 * np.sqrt(k), "wide plain fp32")
+    pre_out = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    e = ops.make_epilogue(bias=bias, pre_out=pre_out, act=1, ld_aux=n)
+    got = ops.gemm_bf16_nt(a, w, epi=e)
+    v = acc + bias.double()
+    assert_close(pre_out, v, 1e-2, 1e-2, "wide pre_out")
+    assert_close(got, gelu64(v), 1e-2, 1e-2, "wide gelu")
+    e = ops.make_epilogue(bias=bias, resid=resid, ld_aux=n)
+    got = ops.gemm_bf16_nt(a, w, out_dtype=torch.float32, epi=e)
+    assert_close(got, v + resid.double(), 1e-4, 2e-3, "wide fp32 out + resid")
+    pre = rnd(m, n, seed=25, dtype=torch.bfloat16).to(DEV)
+    e = ops.make_epilogue(dgelu_pre=pre, ld_aux=n)
+    got = ops.gemm_bf16_nt(a, w, epi=e)
+    assert_close(got, acc * gelu_grad64(pre.double()), 1e-2, 1e-2, "wide dgelu")
+
+
+def test_gemm_bf16_epilogue_gelu_series_accuracy(ops):
+    """The bf16 epilogues evaluate GELU / GELU' as odd polynomial series (csrc/common.h); through an fp32-output GEMM with
+    acc == x (B = I) resp. acc == 1 the series are compared with the erf forms over [-9, 9]: abs error <= 2e-5 / 3e-5."""
+    m, k = 512, 64
+    x = torch.linspace(-9, 9, m * k).reshape(m, k).to(torch.bfloat16)
+    eye = torch.eye(k, dtype=torch.bfloat16)
+    got = ops.gemm_bf16_nt(x.to(DEV), eye.to(DEV), out_dtype=torch.float32, epi=ops.make_epilogue(act=1, ld_aux=k))
+    assert_close(got, gelu64(x.double()), 0, 2e-5, "GELU series")
+    a = torch.zeros(m, k, dtype=torch.bfloat16); a[:, 0] = 1
+    b = torch.zeros(k, k, dtype=torch.bfloat16); b[:, 0] = 1
+    pre = x.to(DEV)
+    got = ops.gemm_bf16_nt(a.to(DEV), b.to(DEV), out_dtype=torch.float32, epi=ops.make_epilogue(dgelu_pre=pre, ld_aux=k))
+    assert_close(got, gelu_grad64(x.double()), 0, 3e-5, "GELU' series")
+
+
 def test_gemm_bf16_nt_asymmetric_identity(ops):
     """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)."""
     n, k = 256, 128
@@ -128,6 +167,26 @@ def test_gemm_bf16_tn(ops, r, m, n):
     out = c0.to(DEV).clone()
     ops.gemm_bf16_tn(a.to(DEV), b.to(DEV), out=out, alpha=0.5, beta=1.0)
     assert_close(out, 0.5 * want + c0.double(), 1e-4, 2e-3 * np.sqrt(r), "tn alpha/beta")
+
+
+@pytest.mark.parametrize("r,m,n", [(64, 128, 128), (200, 136, 264), (4096, 768, 768), (1600, 2304, 768), (51200, 1536, 512)])
+def test_gemm_bf16_tn_fused_colsum(ops, r, m, n):
+    """Bias gradient fused into the weight-gradient GEMM: column sums of A from the staged tiles, with and without a split
+    contraction, ragged M, accumulate on/off; the GEMM result itself must not change."""
+    a, b = rnd(r, m, seed=31, dtype=torch.bfloat16).to(DEV), rnd(r, n, seed=32, dtype=torch.bfloat16).to(DEV)
+    want_c = a.double().t() @ b.double()
+    want_s = a.double().sum(0)
+    cs = torch.full((m,), 7.0, device=DEV)
+    got = ops.gemm_bf16_tn(a, b, colsum_out=cs)
+    assert_close(got, want_c, 1e-4, 2e-3 * np.sqrt(r), "tn + colsum: C")
+    assert_close(cs, want_s, 1e-5, 1e-4 * np.sqrt(r), "tn + colsum: sums")
+    assert torch.equal(got, ops.gemm_bf16_tn(a, b)), "fusing the column sums must not change C"
+    cs2 = torch.full((m,), 3.0, device=DEV)
+    ops.gemm_bf16_tn(a, b, colsum_out=cs2, colsum_beta=1.0)
+    assert_close(cs2, want_s + 3.0, 1e-5, 1e-4 * np.sqrt(r), "tn + colsum: accumulate")
+    cs3 = torch.empty(m, device=DEV)
+    ops.gemm_bf16_tn(a, b, colsum_out=cs3)
+    assert torch.equal(cs, cs3), "column sums are deterministic"
 
 
 def test_gemm_bf16_tn_asymmetric(ops):
