@@ -1,0 +1,134 @@
+"""Build-time audit of the kernels whose accumulators / fragments are managed by inline assembly (csrc/gemm_bf16.hip).
+
+The compiler does not know about (1) the accumulator AGPRs a0..a127 these kernels name directly and (2) the LDS reads in
+flight between an inline `ds_read*` and the hand-placed `s_waitcnt lgkmcnt(0)`.  The audit compiles the file to assembly and
+fails the build if, inside one of those kernels,
+  * the compiler itself touches an AGPR (v_accvgpr_write with a register source, v_accvgpr_mov) - it would be using the
+    accumulators as spill space - or the kernel needs scratch;
+  * any instruction other than an MFMA or another LDS read names a VGPR that is the destination of an LDS read still in flight.
+"""
+from __future__ import annotations
+
+import re
+import subprocess
+
+KERNELS = ("gemm_bf16_nt_big_kernel", "gemm_bf16_tn_big_kernel")
+
+
+def _regs(tok: str):
+    """v5 -> {5}; v[4:7] -> {4,5,6,7}; anything else -> empty."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def _parse(body: str):
+    """-> list of (label | None, op, toks, text, in_asm)."""
+    out, in_asm = [], False
+    for line in body.split("\n"):
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        t = line.split(";")[0].strip()
+        if not t:
+            continue
+        if t.endswith(":") and not t.startswith("."):
+            continue
+        if re.fullmatch(r"\.LBB[\w$]+:", t):
+            out.append((t[:-1], None, [], t, False))
+            continue
+        if t.startswith("."):
+            continue
+        op, _, rest = t.partition(" ")
+        toks = [x.strip() for x in re.split(r"[,\s]+", rest) if x.strip()]
+        out.append((None, op, toks, t, in_asm))
+    return out
+
+
+def audit(asm_text: str):
+    """Forward data-flow over the kernel's basic blocks: the set of VGPRs written by an inline-asm LDS read that has not been
+    waited for (s_waitcnt lgkmcnt(0)) yet; any non-MFMA, non-asm instruction naming one of them is reported."""
+    problems = []
+    for chunk in asm_text.split(".globl")[1:]:
+        name = chunk.split("\n", 1)[0].strip().split()[0]
+        if not any(k in name for k in KERNELS) or ".Lfunc_end" not in chunk:
+            continue
+        ins = _parse(chunk[: chunk.index(".Lfunc_end")])
+        # basic blocks
+        starts = {0}
+        label_at = {}
+        for i, (lab, op, toks, _, _) in enumerate(ins):
+            if lab:
+                starts.add(i)
+                label_at[lab] = i
+            elif op.startswith("s_cbranch") or op == "s_branch" or op == "s_endpgm":
+                starts.add(i + 1)
+        order = sorted(x for x in starts if x < len(ins))
+        end_of = {b: (order[k + 1] if k + 1 < len(order) else len(ins)) for k, b in enumerate(order)}
+
+        def run(b, state, report):
+            cur = set(state)
+            succ = []
+            last_op = None
+            for i in range(b, end_of[b]):
+                lab, op, toks, text, in_asm = ins[i]
+                if lab:
+                    continue
+                last_op = op
+                if op.startswith("scratch_") and report:
+                    problems.append(f"{name}: scratch access `{text}`")
+                if not in_asm and op.startswith("v_accvgpr") and report:
+                    problems.append(f"{name}: compiler-generated AGPR traffic `{text}`")
+                if op == "s_waitcnt" and "lgkmcnt(0)" in text:
+                    cur.clear()
+                    continue
+                if in_asm:
+                    if op.startswith("ds_read"):
+                        cur |= _regs(toks[0])
+                    continue
+                used = set()
+                for x in toks:
+                    used |= _regs(x)
+                if report and used & cur:
+                    problems.append(f"{name}: `{text}` touches VGPRs {sorted(used & cur)} whose inline-asm LDS read is still in flight")
+                if op == "s_branch" or op.startswith("s_cbranch"):
+                    tgt = toks[-1]
+                    if tgt in label_at:
+                        succ.append(label_at[tgt])
+            if last_op != "s_branch" and last_op != "s_endpgm" and end_of[b] < len(ins):
+                succ.append(end_of[b])
+            return cur, succ
+
+        state_in = {b: set() for b in order}
+        work = [order[0]]
+        seen = set()
+        while work:
+            b = work.pop()
+            out, succ = run(b, state_in[b], False)
+            for s_ in succ:
+                if s_ not in state_in:
+                    continue
+                if not out <= state_in[s_] or s_ not in seen:
+                    state_in[s_] |= out
+                    seen.add(s_)
+                    work.append(s_)
+        for b in order:
+            run(b, state_in[b], True)
+    return sorted(set(problems))
+
+
+def check(hipcc: str, source: str, flags: list[str]):
+    r = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", source, "-o", "-"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"asm audit: hipcc failed\n{r.stderr}")
+    problems = audit(r.stdout)
+    if problems:
+        raise RuntimeError("asm audit of the inline-assembly GEMM kernels failed:\n  " + "\n  ".join(problems[:20]))
+    return True

@@ -18,7 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsparsify_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-spill-vgpr-to-agpr=0: two GEMM kernels own the AGPRs (accumulators named directly in inline assembly); the register
+# allocator must never use them as VGPR spill space (csrc/gemm_bf16.hip, audited by _asm_check.py)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
 
 
 def _newer(target: str, deps) -> bool:
@@ -54,6 +56,12 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
             for warn in ex.map(run, jobs):
                 if warn.strip() and verbose:
                     print(warn)
+        gemm = os.path.join(CSRC, "gemm_bf16.hip")
+        if any(gemm in cmd for cmd in jobs):   # the kernels with hand-managed AGPRs / in-flight LDS reads are audited whenever they are rebuilt
+            from ._asm_check import check
+            check(HIPCC, gemm, [f for f in FLAGS if f != "-fPIC"])
+            if verbose:
+                print("asm audit of gemm_bf16.hip: ok", flush=True)
     if force or jobs or _newer(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -6,6 +6,7 @@
 // GELU, GELU', and the residual adds are fused into the GEMM epilogues; LayerNorm backward also emits the
 // `dtype` copy of the residual gradient that the next GEMM consumes.
 #include "common.h"
+#include <stdlib.h>
 #include "gemm_epilogue.h"
 
 int sc_gemm_f32_launch(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
@@ -154,8 +155,10 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
     SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss, bf ? d->g_b_fc1 : nullptr));
-    if (!bf) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
+    static const bool fuse_cs = [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum pass (A/B runs)
+    const bool fcs = bf && fuse_cs;
+    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss, fcs ? d->g_b_fc1 : nullptr));
+    if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
     // dx_mid = dx_out + LN2'(d_ln); the same kernel emits the operand copy and the out_proj bias gradient (column sums of dx_mid).
     // With a side stream the copy must not land in the buffer `g` that the side stream may still be reading (internal-cast case).
@@ -169,8 +172,8 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
     SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss, bf ? d->g_b_qkv : nullptr));
-    if (!bf) SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
+    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss, fcs ? d->g_b_qkv : nullptr));
+    if (!fcs) SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
     // dx_in = dx_mid + LN1'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,

@@ -17,6 +17,9 @@
 #include "gemm_epilogue.h"
 #include <stdlib.h>
 
+extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
+                         void* stream);
+
 namespace {
 
 constexpr int TILE = 128, KSTEP = 64;
@@ -367,9 +370,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
 // see are handled by hand: s_waitcnt lgkmcnt before the first MFMA that consumes a fragment, s_nop before the read-back.
 constexpr int B_M = 256, B_N = 256, B_STAGE = (B_M + B_N) * 128, B_A = B_M * 128, B_GROUP_M = 8, B_GROUP_N = 4, B_LDS = 8 * 64 * 68 * 4;
 
+// Clobber list of the accumulator AGPRs: attached to EVERY inline-assembly statement that reads or writes them, so that the
+// register allocator (which freely parks long-lived values in AGPRs on gfx90a+) can keep nothing of its own in a0..a127
+// across the main loop or across the accumulator read-back.
+#define SC_ACC_AGPRS \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+
 template <int F>
 __device__ __forceinline__ void ntb_mfma(const bf16x8 (&a)[8], const bf16x8 (&b)[4]) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3));
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3) : SC_ACC_AGPRS);
 }
 template <int OFF>
 __device__ __forceinline__ void ntb_read(bf16x8& dst, unsigned base) {
@@ -389,14 +405,14 @@ __device__ __forceinline__ void ntb_substep(bf16x8 (&a)[8], const bf16x8 (&b)[4]
 template <int N>
 __device__ __forceinline__ void ntb_zero() {
     asm volatile("v_accvgpr_write_b32 a[%0], 0\n v_accvgpr_write_b32 a[%1], 0\n v_accvgpr_write_b32 a[%2], 0\n v_accvgpr_write_b32 a[%3], 0"
-                 : : "n"(N), "n"(N + 1), "n"(N + 2), "n"(N + 3));
+                 : : "n"(N), "n"(N + 1), "n"(N + 2), "n"(N + 3) : SC_ACC_AGPRS);
     if constexpr (N + 4 < 128) ntb_zero<N + 4>();
 }
 template <int T>
 __device__ __forceinline__ f32x4 ntb_acc() {   // accumulator tile T = 4 i + j
     f32x4 v;
     asm volatile("v_accvgpr_read_b32 %0, a[%4]\n v_accvgpr_read_b32 %1, a[%5]\n v_accvgpr_read_b32 %2, a[%6]\n v_accvgpr_read_b32 %3, a[%7]"
-                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3));
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3) : SC_ACC_AGPRS);
     return v;
 }
 template <int T, int H>
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
         gb[q] = p.B + (int64_t)min(n0 + wave * 32 + q * 8 + srow, p.N - 1) * p.ldb + schunk * 8;
     }
     // reserves a0..a127 in the kernel descriptor (the compiler allocates what it sees clobbered) and clears them
-    asm volatile("" ::: "a0", "a127");
+    asm volatile("" ::: SC_ACC_AGPRS);
     ntb_zero<0>();
 
     const int nk = p.K / KSTEP;
@@ -450,19 +466,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     // Stage S holds tile KT.  Sub-step 0 of tile KT runs while the fragments of its sub-step 1 are read (stage S); the barrier
     // publishes tile KT+1 (vmcnt(0): the only tile in flight) and retires every read of stage S (lgkmcnt(0)), so the LDS-DMA
     // of tile KT+2 may overwrite stage S right behind it; sub-step 1 then reads the first fragments of tile KT+1 from S^1.
-#define NTB_BODY(S, KT, A_S1, B_S1, A_N0, B_N0)                                                       \
+#define NTB_FULL(S, KT, A_S1, B_S1, A_N0, B_N0)   /* tile KT is not the last one */                   \
     do {                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
         ntb_substep<0, true>(a, b0, b1, A_S1, B_S1);                                                  \
-        if ((KT) + 1 < nk) {                                                                          \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                               \
-            __builtin_amdgcn_s_barrier();                                                             \
-            if ((KT) + 2 < nk) NTB_STAGE(S, (KT) + 2);                                                \
-            ntb_substep<0, true>(a, b1, b0, A_N0, B_N0);                                              \
-        } else {                                                                                      \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-            ntb_substep<0, false>(a, b1, b0, A_N0, B_N0);                                             \
-        }                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) NTB_STAGE(S, (KT) + 2);                                                    \
+        ntb_substep<0, true>(a, b1, b0, A_N0, B_N0);                                                  \
+    } while (0)
+#define NTB_LAST(A_S1, B_S1)                                                                          \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        ntb_substep<0, true>(a, b0, b1, A_S1, B_S1);                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        ntb_substep<0, false>(a, b1, b0, 0u, 0u);                                                     \
     } while (0)
 
     bf16x8 a[8], b0[4], b1[4];
@@ -473,12 +491,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     ntb_read<0>(b0[0], fb00); ntb_read<2048>(b0[1], fb00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(b0[3], fb00);
     ntb_read<0>(a[0], fa00); ntb_read<2048>(a[1], fa00); ntb_read<4096>(a[2], fa00); ntb_read<6144>(a[3], fa00);
     ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
-    for (int kt = 0; kt < nk; kt += 2) {
-        NTB_BODY(0, kt, fa01, fb01, fa10, fb10);
-        if (kt + 1 < nk) NTB_BODY(1, kt + 1, fa11, fb11, fa00, fb00);
+    // the loop only runs bodies that are followed by another tile, so every exit edge leads to code that starts with a wait:
+    // no inline-asm LDS read is in flight when compiler-scheduled code (the epilogue) begins
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        NTB_FULL(0, kt, fa01, fb01, fa10, fb10);
+        NTB_FULL(1, kt + 1, fa11, fb11, fa00, fb00);
     }
-    asm volatile("s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
-#undef NTB_BODY
+    const bool two_left = kt + 1 < nk;   // one straight-line tail (no second copy of the last body that a path could bypass)
+    if (two_left) NTB_FULL(0, kt, fa01, fb01, fa10, fb10);
+    NTB_LAST(two_left ? fa11 : fa01, two_left ? fb11 : fb01);
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // no LDS read in flight on any exit edge; the last MFMAs retire before the accumulators are read back
+#undef NTB_LAST
+#undef NTB_FULL
 #undef NTB_STAGE
 
     // Epilogue: as in the 256x128 kernel (per-wave 64x64 LDS slab, row-major 16-byte pieces), two passes of 64 rows per wave.
@@ -957,6 +982,169 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(GemmBf16Params 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, 256x256, AGPR accumulators
+// The weight-gradient GEMM with the structure of the NT 256x256 kernel above: 8 waves as 2(M) x 4(N), each wave a 128x64
+// sub-tile whose 128 accumulator registers are the physical AGPRs a0..a127 (same tile -> register map, same hand-placed
+// MFMA / LDS-read order).  Both operands are contraction-strided, so a K-tile is 64 rows r of 256 columns (512 B), staged
+// row-major with the 32-B slot swizzle of tn_swz and read back transposed: one MFMA operand = two ds_read_b64_tr_b16.
+// LDS: [A stage 0 | A stage 1 | B stage 0 | B stage 1], 32 KiB each, so that both stages of an operand are reachable from one
+// per-lane base register through the 16-bit DS offset.  The contraction is split over workgroups (one round of <= 256
+// workgroups); R must be a multiple of 64.  (The fused column sums of A live in the 128x128 kernel only: with the accumulators
+// in AGPRs this kernel has 128 VGPRs, and 8 running sums + 16 staging registers do not fit next to 64 fragment registers;
+// the launcher runs the separate column-sum pass instead.)
+constexpr int TB_OPER = 32768;   // one operand tile: 64 rows x 512 B
+
+// LDS-DMA with a uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset, written out so that the compiler cannot widen
+// the eight offsets back into eight 64-bit pointers (16 VGPRs this kernel does not have).  M0 = LDS destination of the wave.
+__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");   // M0 is written; this kernel has no compiler-generated M0 user
+}
+
+// Fragments are kept as four dwords: the two 8-byte halves of an operand are joined at dword granularity (a pure register
+// sequence).  With 16-bit element vectors the join is lowered to v_bfi/v_perm read-modify-writes ON the destination registers,
+// which race with the LDS return of the very reads that fill them.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+template <int OFF, int XOR>
+__device__ __forceinline__ i32x4 tnb_read(unsigned base) {   // fragment at (base ^ XOR) + OFF: rows .. and rows + 4 (2048 B further)
+    i32x2 lo, hi;
+    if constexpr (XOR == 0) {
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(lo), "=&v"(hi) : "v"(base), "n"(OFF), "n"(OFF + 2048) : "memory");
+    } else {   // the XOR is done inside the statement: left to the compiler, the 12 fragment addresses are hoisted into 12 VGPRs
+        unsigned tmp;
+        asm volatile("v_xor_b32 %2, %5, %3\n\tds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %2 offset:%6"
+                     : "=&v"(lo), "=&v"(hi), "=&v"(tmp) : "v"(base), "n"(OFF), "n"(XOR), "n"(OFF + 2048) : "memory");
+    }
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+template <int F>
+__device__ __forceinline__ void tnb_mfma(const i32x4 (&a)[8], const i32x4 (&b)[4]) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3) : SC_ACC_AGPRS);
+}
+// one sub-step (32 rows of the contraction): 8 groups of 4 MFMAs; when LOAD, group I is followed by the reads that reload
+// a[I] for the next sub-step in place and, for I < 4, B fragment I of the next sub-step into the other B set.
+// OFF = byte offset of the next sub-step's rows inside the operand's two-stage area.
+template <int I, bool LOAD, int OFF>
+__device__ __forceinline__ void tnb_substep(i32x4 (&a)[8], const i32x4 (&b)[4], i32x4 (&bn)[4], unsigned ab0, unsigned bb0) {
+    tnb_mfma<4 * I>(a, b); tnb_mfma<4 * I + 1>(a, b); tnb_mfma<4 * I + 2>(a, b); tnb_mfma<4 * I + 3>(a, b);
+    if constexpr (LOAD) {
+        a[I] = tnb_read<OFF, (I << 5)>(ab0);          // fragment I: 16-byte slot index ^ 2 I (see the base computation)
+        if constexpr (I < 4) bn[I] = tnb_read<OFF, (I << 5)>(bb0);
+    }
+    if constexpr (I + 1 < 8) tnb_substep<I + 1, LOAD, OFF>(a, b, bn, ab0, bb0);
+}
+template <int T>
+__device__ __forceinline__ void tnb_store(const GemmBf16Params& p, int split, int mrow, int ncol) {   // tile T = 4 i + j of the wave
+    const int m = mrow + 16 * (T / 4), n = ncol + 16 * (T % 4);
+    if (m < p.M && n < p.N) {
+        const f32x4 acc = ntb_acc<T>();
+        if (p.partial) {
+            *(f32x4*)(p.partial + ((int64_t)split * p.M + m) * p.N + n) = acc;
+        } else {
+            float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+            f32x4 v = acc * p.epi.alpha;
+            if (p.epi.beta != 0.f) v += *(const f32x4*)cp * p.epi.beta;
+            *(f32x4*)cp = v;
+        }
+    }
+    if constexpr (T + 1 < 32) tnb_store<T + 1>(p, split, mrow, ncol);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TB_OPER];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, ntiles * p.splits);
+    const int split = id / ntiles, tile = id % ntiles;
+    const int m0 = (tile / p.tiles_n) * B_M, n0 = (tile % p.tiles_n) * B_N;
+    const int kt_begin = split * p.k_per_split;
+    const int kt_end = min(p.K / KSTEP, kt_begin + p.k_per_split);
+    const int nk = kt_end - kt_begin;
+
+    // staging: one wave instruction = 2 rows x 512 B; lane -> (row l >> 5, slot l & 31); wave w owns rows 8 w .. 8 w + 7.
+    // Per-lane 32-bit byte offsets against a uniform (SGPR) base that advances by one K-tile: 8 VGPRs instead of 8 pointers.
+    unsigned oa[4], ob[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 8 + q * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ tn_swz(r);
+        oa[q] = (unsigned)((r * p.lda + min(m0 + c * 8, p.M - 8)) * 2);
+        ob[q] = (unsigned)((r * p.ldb + min(n0 + c * 8, p.N - 8)) * 2);
+    }
+    const char* a_tile0 = (const char*)p.A + (int64_t)kt_begin * KSTEP * p.lda * 2;
+    const char* b_tile0 = (const char*)p.B + (int64_t)kt_begin * KSTEP * p.ldb * 2;
+    const int64_t a_step = (int64_t)KSTEP * p.lda * 2, b_step = (int64_t)KSTEP * p.ldb * 2;   // bytes per K-tile
+
+    asm volatile("" ::: SC_ACC_AGPRS);   // reserve the accumulator AGPRs in the kernel descriptor
+    ntb_zero<0>();
+
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    const int swz = (q4 | ((g & 1) << 2)) << 1;           // == tn_swz(row) for every row this lane reads
+    // Fragment i of A: slot (wm 16 + 2 i + (pp >> 1)) ^ swz of row 8 g + q4 (+ 32 s + 4 h).  swz only has bits 1..3, 2 i too, and
+    // the LDS array starts on a 1-KiB boundary, so fragment i sits at (base of fragment 0) ^ (i << 5): one base register per operand.
+    const unsigned ab0 = lds0 + (8 * g + q4) * 512 + (((wm * 16 + (pp >> 1)) ^ swz) << 4) + ((pp & 1) << 3);
+    const unsigned bb0 = lds0 + 2 * TB_OPER + (8 * g + q4) * 512 + (((wn * 8 + (pp >> 1)) ^ swz) << 4) + ((pp & 1) << 3);
+
+#define TNB_STAGE(S, KT)                                                                              \
+    do {                                                                                              \
+        const unsigned la__ = lds0 + (S) * TB_OPER + (wave * 8) * 512;                                \
+        const char* ak__ = a_tile0 + (KT) * a_step;                                                   \
+        const char* bk__ = b_tile0 + (KT) * b_step;                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16_saddr(ak__, oa[q], la__ + q * 1024);     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16_saddr(bk__, ob[q], la__ + 2 * TB_OPER + q * 1024); \
+    } while (0)
+    // The fragment registers are written by inline-assembly LDS reads the compiler knows nothing about: between such a read and
+    // its s_waitcnt no compiler-scheduled vector code may touch them (audited at build time, _asm_check.py).
+    // Stage S holds K-tile KT (relative to kt_begin).  Same pipeline as the NT kernel: sub-step 0 || reads of sub-step 1 (stage S),
+    // barrier (tile KT+1 landed, every read of stage S retired), LDS-DMA of tile KT+2 into stage S, sub-step 1 || reads of the
+    // first fragments of tile KT+1 (stage S^1).
+#define TNB_FULL(S, KT)   /* tile KT is not the last one of this workgroup */                          \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        tnb_substep<0, true, (S) * TB_OPER + 16384>(a, b0, b1, ab0, bb0);                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) TNB_STAGE(S, (KT) + 2);                                                    \
+        tnb_substep<0, true, ((S) ^ 1) * TB_OPER>(a, b1, b0, ab0, bb0);                               \
+    } while (0)
+#define TNB_LAST(AB, BB)   /* the stage is a run-time offset folded into the bases */                  \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        tnb_substep<0, true, 16384>(a, b0, b1, AB, BB);                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        tnb_substep<0, false, 0>(a, b1, b0, AB, BB);                                                  \
+    } while (0)
+
+    i32x4 a[8], b0[4], b1[4];
+    TNB_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) TNB_STAGE(1, 1);
+    b0[0] = tnb_read<0, 0>(bb0); b0[1] = tnb_read<0, 32>(bb0); b0[2] = tnb_read<0, 64>(bb0); b0[3] = tnb_read<0, 96>(bb0);
+    a[0] = tnb_read<0, 0>(ab0); a[1] = tnb_read<0, 32>(ab0); a[2] = tnb_read<0, 64>(ab0); a[3] = tnb_read<0, 96>(ab0);
+    a[4] = tnb_read<0, 128>(ab0); a[5] = tnb_read<0, 160>(ab0); a[6] = tnb_read<0, 192>(ab0); a[7] = tnb_read<0, 224>(ab0);
+    int kt = 0;   // as in the NT kernel: every loop exit leads to code that starts with a wait
+    for (; kt + 2 < nk; kt += 2) {
+        TNB_FULL(0, kt);
+        TNB_FULL(1, kt + 1);
+    }
+    const bool two_left = kt + 1 < nk;
+    if (two_left) TNB_FULL(0, kt);
+    const unsigned last_stage = two_left ? TB_OPER : 0;
+    TNB_LAST(ab0 + last_stage, bb0 + last_stage);
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // no LDS read in flight on any exit edge; the last MFMAs retire before the accumulators are read back
+#undef TNB_LAST
+#undef TNB_FULL
+#undef TNB_STAGE
+
+    // D[n][m]: lane holds m = .. + (lane & 15), n = .. + 4 (lane >> 4) + reg
+    tnb_store<0>(p, split, m0 + wm * 128 + i16, n0 + wn * 64 + 4 * g);
+}
+
 // C = alpha * sum_s partial[s] + beta * C   (fixed order); optionally also cs_out = cs_beta * cs_out + sum_s cs_partial[s]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, int64_t mn, int n, float* c, int64_t ldc,
                                                             float alpha, float beta, const float* cs_partial, float* cs_out, int m_len, float cs_beta) {
@@ -976,26 +1164,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
     }
 }
 
-bool tn_small() {
-    // default: the 128x128 2-stage kernel at 2 workgroups/CU (600-700 TF); SC_GEMM_TN=256 selects the 256x128 3-stage variant,
-    // which measured 540-650 TF on the same shapes (both are load-latency bound: SQ_WAIT_ANY 63 %, LDS conflicts 0)
-    static const bool v = [] { const char* e = getenv("SC_GEMM_TN"); return !(e && e[0] == '2'); }();
+// TN kernel choice.  Default: the 256x256 AGPR kernel when the output has at least 6 such tiles and R % 64 == 0, otherwise the
+// 128x128 2-stage kernel at 2 workgroups/CU.  SC_GEMM_TN=128 forces the latter everywhere, SC_GEMM_TN=256 selects the older
+// 256x128 3-stage variant for calls without fused column sums (both kept for A/B runs).
+enum TnKind { TN_SMALL = 0, TN_256 = 1, TN_BIG = 2 };
+int tn_env() {
+    static const int v = [] { const char* e = getenv("SC_GEMM_TN"); return !e ? 0 : (e[0] == '1' ? 128 : (e[0] == '2' ? 256 : 0)); }();
     return v;
 }
-
-int tn_splits(int64_t m, int64_t n, int64_t r) {
+void tn_plan_small(int64_t m, int64_t n, int64_t r, int& kind, int& splits) {
     const int64_t nk = sc_cdiv(r, KSTEP);
+    int64_t s = sc_cdiv(768, sc_cdiv(m, TILE) * sc_cdiv(n, TILE));
+    const int64_t cap = nk / 4 > 1 ? nk / 4 : 1;
+    if (s > cap) s = cap;
+    if (s > 32) s = 32;
+    kind = TN_SMALL;
+    splits = (int)(s < 1 ? 1 : s);
+}
+void tn_plan(int64_t m, int64_t n, int64_t r, bool colsum, int& kind, int& splits) {
+    const int64_t nk = sc_cdiv(r, KSTEP);
+    const int64_t tiles_big = sc_cdiv(m, B_M) * sc_cdiv(n, B_N);
     int64_t s;
-    if (tn_small()) {
-        s = sc_cdiv(768, sc_cdiv(m, TILE) * sc_cdiv(n, TILE));
+    if (tn_env() == 0 && r % KSTEP == 0 && tiles_big >= 6) {
+        kind = TN_BIG;
+        s = 256 / tiles_big;       // one round of at most 256 workgroups
+    } else if (tn_env() == 256 && !colsum) {
+        kind = TN_256;
+        s = 256 / (sc_cdiv(m, T_M) * sc_cdiv(n, T_N));
     } else {
-        const int64_t tiles = sc_cdiv(m, T_M) * sc_cdiv(n, T_N);
-        s = 256 / tiles;   // fill the 256 CUs once: no partially filled second round
+        kind = TN_SMALL;
+        s = sc_cdiv(768, sc_cdiv(m, TILE) * sc_cdiv(n, TILE));
     }
     const int64_t cap = nk / 4 > 1 ? nk / 4 : 1;
     if (s > cap) s = cap;
     if (s > 32) s = 32;
-    return (int)(s < 1 ? 1 : s);
+    splits = (int)(s < 1 ? 1 : s);
 }
 
 }  // namespace
@@ -1045,7 +1248,12 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
 }
 
 size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r) {
-    const int s = tn_splits(m, n, r);
+    int kind, s0, s1;
+    int s2;
+    tn_plan(m, n, r, false, kind, s0);
+    tn_plan(m, n, r, true, kind, s1);
+    tn_plan_small(m, n, r, kind, s2);
+    const int s = s0 > s1 ? (s0 > s2 ? s0 : s2) : (s1 > s2 ? s1 : s2);
     return s > 1 ? (size_t)s * (m * n + m) * sizeof(float) : 0;   // partial C slabs + partial column sums of A
 }
 
@@ -1061,9 +1269,13 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     p.M = (int)m; p.N = (int)n; p.K = (int)r;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     SC_REQUIRE(!colsum_a || sc_aligned(colsum_a, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: colsum must be 16-byte aligned");
-    const bool small = tn_small() || colsum_a != nullptr;   // the fused column sums live in the 128x128 kernel
-    p.tiles_m = (int)sc_cdiv(m, small ? TILE : T_M); p.tiles_n = (int)sc_cdiv(n, small ? TILE : T_N);
-    p.splits = tn_splits(m, n, r);
+    int kind;
+    tn_plan(m, n, r, colsum_a != nullptr, kind, p.splits);
+    if (kind == TN_BIG && colsum_a && (colsum_beta != 0.f && colsum_beta != 1.f)) kind = TN_SMALL;   // the separate pass only knows overwrite / accumulate
+    if (kind == TN_BIG && colsum_a && ws_bytes < (size_t)1024 * m * sizeof(float)) kind = TN_SMALL;    // its partials reuse ws
+    if (kind == TN_SMALL) { int k2; tn_plan_small(m, n, r, k2, p.splits); }
+    const int tm = kind == TN_SMALL ? TILE : (kind == TN_BIG ? B_M : T_M), tn = kind == TN_SMALL ? TILE : (kind == TN_BIG ? B_N : T_N);
+    p.tiles_m = (int)sc_cdiv(m, tm); p.tiles_n = (int)sc_cdiv(n, tn);
     p.cs_out = colsum_a; p.cs_partial = nullptr; p.cs_beta = colsum_beta;
     const int64_t nk = sc_cdiv(r, KSTEP);
     p.k_per_split = (int)sc_cdiv(nk, p.splits);
@@ -1077,7 +1289,9 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
         if (colsum_a) p.cs_partial = (float*)ws + (size_t)p.splits * m * n;
     }
     const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n * p.splits);
-    if (small) hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+    if (kind == TN_BIG) { p.cs_out = nullptr; p.cs_partial = nullptr; }   // column sums: separate pass below
+    if (kind == TN_SMALL) hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+    else if (kind == TN_BIG) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel, dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3(grid), dim3(512), 0, stream, p);
     SC_CHECK_LAUNCH();
     if (p.splits > 1) {
@@ -1086,6 +1300,8 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
                            alpha, beta, p.cs_partial, colsum_a, (int)m, colsum_beta);
         SC_CHECK_LAUNCH();
     }
+    if (kind == TN_BIG && colsum_a)   // stream-ordered behind the reduction, so the partial-slab workspace is free again
+        return sc_colsum(a, SC_BF16, r, m, lda, colsum_a, colsum_beta != 0.f ? 1 : 0, ws, ws_bytes, (void*)stream);
     return SC_OK;
 }
 

@@ -157,7 +157,7 @@ def test_gemm_bf16_nt_epilogue(ops):
     assert_close(got, acc * gelu_grad64(pre.double()), 1e-2, 1e-2, "bf16 dgelu")
 
 
-@pytest.mark.parametrize("r,m,n", [(64, 128, 128), (200, 136, 264), (4096, 768, 768), (1600, 2304, 768)])
+@pytest.mark.parametrize("r,m,n", [(64, 128, 128), (200, 136, 264), (4096, 768, 768), (1600, 2304, 768), (640, 776, 520), (64, 1536, 512)])
 def test_gemm_bf16_tn(ops, r, m, n):
     a, b = rnd(r, m, seed=21, dtype=torch.bfloat16), rnd(r, n, seed=22, dtype=torch.bfloat16)
     want = a.double().t() @ b.double()
@@ -169,7 +169,7 @@ def test_gemm_bf16_tn(ops, r, m, n):
     assert_close(out, 0.5 * want + c0.double(), 1e-4, 2e-3 * np.sqrt(r), "tn alpha/beta")
 
 
-@pytest.mark.parametrize("r,m,n", [(64, 128, 128), (200, 136, 264), (4096, 768, 768), (1600, 2304, 768), (51200, 1536, 512)])
+@pytest.mark.parametrize("r,m,n", [(64, 128, 128), (200, 136, 264), (4096, 768, 768), (1600, 2304, 768), (51200, 1536, 512), (640, 776, 520), (192, 1536, 512)])
 def test_gemm_bf16_tn_fused_colsum(ops, r, m, n):
     """Bias gradient fused into the weight-gradient GEMM: column sums of A from the staged tiles, with and without a split
     contraction, ragged M, accumulate on/off; the GEMM result itself must not change."""
