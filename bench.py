@@ -68,40 +68,72 @@ def reference_config(prefix, model, global_batch, precision):
 
 
 def step_gemm_launches(cfg, batch, k_patch, grid):
-    """(M, N, K) x repetitions of every bf16 NT GEMM launch of one training step (forward linears + activation-gradient GEMMs)."""
+    """((M, N, K), epilogue, repetitions) of every bf16 NT GEMM launch of one training step: the four forward linears of a
+    block with the epilogues the step fuses into them, and the four activation-gradient GEMMs."""
     launches = []
     for rows, w, layers in ((batch * (grid ** 2 + 1), cfg["v_width"], cfg["v_layers"]), (batch * cfg["ctx"], cfg["t_width"], cfg["t_layers"])):
-        shapes = [(rows, 3 * w, w), (rows, w, w), (rows, 4 * w, w), (rows, w, 4 * w),      # fwd: qkv, out, fc1, fc2
-                  (rows, w, 3 * w), (rows, w, w), (rows, w, 4 * w), (rows, 4 * w, w)]      # dX of the same four
-        launches += [(s, layers) for s in shapes]
+        shapes = [((rows, 3 * w, w), "bias"), ((rows, w, w), "bias+resid"), ((rows, 4 * w, w), "bias+gelu+pre"), ((rows, w, 4 * w), "bias+resid"),   # fwd: qkv, out, fc1, fc2
+                  ((rows, w, 3 * w), "plain"), ((rows, w, w), "plain"), ((rows, w, 4 * w), "plain"), ((rows, 4 * w, w), "dgelu")]                    # dX of the same four
+        launches += [(s, e, layers) for s, e in shapes]
     if k_patch % 64 == 0:
-        launches.append(((batch * grid ** 2, cfg["v_width"], k_patch), 1))
+        launches.append(((batch * grid ** 2, cfg["v_width"], k_patch), "plain", 1))
     return launches
 
 
+def gemm_launch_operands(m, n, k, kind, device):
+    """Operands of one replayed NT GEMM launch with the epilogue the training step fuses into it."""
+    from sparsify_clip_amd import ops
+    a = torch.randn(m, k, device=device).to(torch.bfloat16)
+    b = torch.randn(n, k, device=device).to(torch.bfloat16)
+    bias = torch.randn(n, device=device)
+    epi, out_dtype, keep = None, torch.bfloat16, None
+    if kind == "bias":
+        epi = ops.make_epilogue(bias=bias, ld_aux=n)
+    elif kind == "bias+resid":
+        keep = torch.randn(m, n, device=device)
+        epi, out_dtype = ops.make_epilogue(bias=bias, resid=keep, ld_aux=n), torch.float32
+    elif kind == "bias+gelu+pre":
+        keep = torch.empty(m, n, dtype=torch.bfloat16, device=device)
+        epi = ops.make_epilogue(bias=bias, pre_out=keep, act=1, ld_aux=n)
+    elif kind == "dgelu":
+        keep = torch.randn(m, n, device=device).to(torch.bfloat16)
+        epi = ops.make_epilogue(dgelu_pre=keep, ld_aux=n)
+    out = torch.empty(m, n, dtype=out_dtype, device=device)
+    return a, b, out, epi, keep
+
+
+def gemm_launch_bytes(m, n, k, kind):
+    """Algorithmic HBM bytes of one launch: A + B once, C once, plus the epilogue's own operands."""
+    base = 2 * (m * k + n * k)
+    if kind == "bias+resid":
+        return base + 4 * m * n + 4 * m * n            # fp32 residual in, fp32 C out
+    if kind in ("bias+gelu+pre", "dgelu"):
+        return base + 2 * m * n + 2 * m * n            # bf16 C out + saved pre-activation out / in
+    return base + 2 * m * n
+
+
 def gemm_roofline(model, device):
-    """Replay the bf16 NT GEMM launches of one training step with a HIP event pair around each launch on the launch stream;
+    """Replay the bf16 NT GEMM launches of one training step - same shapes, same fused epilogues (bias, GELU + saved
+    pre-activation, fp32 residual add, GELU' multiply) - with a HIP event pair around each launch on the launch stream;
     algorithmic FLOPs = 2*M*N*K per launch.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes over the
     same launch set (tools/gpu_pmc_traffic.sh: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE), or null when absent."""
     from sparsify_clip_amd import ops
     launches = step_gemm_launches(model.cfg, model.visual.batch, model.k_patch, model.grid)
     total_flops, total_ms, count = 0.0, 0.0, 0
-    for (m, n, k), reps in launches:
-        a = torch.randn(m, k, device=device).to(torch.bfloat16)
-        b = torch.randn(n, k, device=device).to(torch.bfloat16)
-        out = torch.empty(m, n, dtype=torch.bfloat16, device=device)
-        ops.gemm_bf16_nt(a, b, out=out)
+    for (m, n, k), kind, reps in launches:
+        a, b, out, epi, keep = gemm_launch_operands(m, n, k, kind, device)
+        ops.gemm_bf16_nt(a, b, out=out, epi=epi)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         for s, e in evs:
             s.record()
-            ops.gemm_bf16_nt(a, b, out=out)
+            ops.gemm_bf16_nt(a, b, out=out, epi=epi)
             e.record()
         torch.cuda.synchronize()
         ms = sorted(s.elapsed_time(e) for s, e in evs)[1]
         total_flops += 2.0 * m * n * k * reps
         total_ms += ms * reps
         count += reps
-        del a, b, out
+        del a, b, out, keep, epi
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
@@ -110,9 +142,11 @@ def gemm_roofline(model, device):
             t = json.load(f)
         if t.get("launches") == count and t.get("local_batch") == model.visual.batch:
             traffic = t["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt256_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt (256x256 AGPR kernel + 256x128 kernel; every NT launch of one step with its fused epilogue)",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": count,
-            "avg_launch_us": round(total_ms * 1e3 / count, 1), "flops_per_launch_avg": total_flops / count}
+            "avg_launch_us": round(total_ms * 1e3 / count, 1), "flops_per_launch_avg": total_flops / count,
+            "algorithmic_bytes_per_launch_avg": sum(gemm_launch_bytes(m, n, k, kind) * reps for (m, n, k), kind, reps in launches) / count}
 
 
 def cpu_baseline(cfg, model_name, batch):

@@ -21,6 +21,11 @@ bool use_mfma() {
     static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return !(e && e[0] == 'v'); }();
     return on;
 }
+// SC_ATTENTION=wave: the backward at seq <= 64 on the one-wave-per-head kernel instead of one workgroup per head (A/B runs)
+bool wave_per_head() {
+    static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return e && e[0] == 'w'; }();
+    return on;
+}
 
 constexpr int HD = 64;        // head dim
 constexpr int HDP = HD + 4;   // padded LDS row (floats): 272-B stride -> conflict-free ds_read_b128 across rows
@@ -179,6 +184,7 @@ extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t b
     SC_TRY(check("sc_attention_fwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && out, SC_ERR_ARG, "sc_attention_fwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
+        // forward, seq <= 80: one wave per head measured faster (81 / 86 us vs 85 / 112 us at the step's two shapes)
         int rc = sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc == 1) rc = sc_attention_long_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc != 1) return rc;
@@ -204,7 +210,8 @@ extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv,
     SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
-        int rc = sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
+        // backward: one workgroup per head wins at seq <= 64 (262 vs 303 us, S = 50), one wave per head at 64 < seq <= 80 (286 vs 341 us, S = 77)
+        int rc = (wave_per_head() || seq > 64) ? sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream) : 1;
         if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc != 1) return rc;
     }

@@ -12,8 +12,8 @@ using namespace attn;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
-template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, float scale) {
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, float scale) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;
@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* qkv, b
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int64_t ld = 3 * (int64_t)W;
     const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
-    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 256);
-    stage_head_block(Vs, qb + 2 * W, ld, S, NT * 16, tid, 256);
+    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Vs, qb + 2 * W, ld, S, NT * 16, tid, 64 * NW);
     __syncthreads();
     const int g = lane >> 4, c16 = lane & 15;
     const int n_it = (S + 15) >> 4;
-    for (int it = wave; it < n_it; it += 4) {
+    for (int it = wave; it < n_it; it += NW) {
         const bf16x8 q0 = row_frag_global(qb, ld, it, 0, lane, S), q1 = row_frag_global(qb, ld, it, 1, lane, S);
         const int i = it * 16 + c16;
         f32x4 sc[NT + 1];
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* qkv, b
     }
 }
 
-template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_long_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale) {
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;
@@ -102,15 +102,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_long_kernel(const bf16_t* qkv
     const bf16_t* vb = qb + 2 * W;
     const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
     bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
-    stage_head_block(Qs, qb, ld, S, NT * 16, tid, 256);
-    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 256);
-    stage_head_block(Os, dob, W, S, NT * 16, tid, 256);
+    stage_head_block(Qs, qb, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Os, dob, W, S, NT * 16, tid, 64 * NW);
     __syncthreads();
     const int g = lane >> 4, c16 = lane & 15;
     const int n_t = (S + 15) >> 4;
 
     // ---------------- pass 1: lane = query row i
-    for (int it = wave; it < n_t; it += 4) {
+    for (int it = wave; it < n_t; it += NW) {
         const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
         const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
         const int i = it * 16 + c16;
@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_long_kernel(const bf16_t* qkv
         }
     }
     // tiles of padding queries (none when n_t == NT) must read as "no contribution" in pass 2
-    for (int i = n_t * 16 + tid; i < NT * 16; i += 256) st_m[i] = st_il[i] = st_dl[i] = 0.f;
+    for (int i = n_t * 16 + tid; i < NT * 16; i += 64 * NW) st_m[i] = st_il[i] = st_dl[i] = 0.f;
     __syncthreads();   // every query tile's statistics are in LDS
 
     // ---------------- pass 2: lane = key row j
-    for (int jt = wave; jt < n_t; jt += 4) {
+    for (int jt = wave; jt < n_t; jt += NW) {
         const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
         const bf16x8 v0 = row_frag_global(vb, ld, jt, 0, lane, S), v1 = row_frag_global(vb, ld, jt, 1, lane, S);
         const int j = jt * 16 + c16;
@@ -248,38 +248,55 @@ int reserve_lds(K kernel, size_t bytes) {
 
 constexpr int NT_LONG = 17;   // 272 rows: S <= 272
 
-}  // namespace
-
-// bf16, 80 < seq <= 272.  Returns 1 when the shape is not covered.
-int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
-    if (seq > NT_LONG * 16) return 1;
-    const size_t lds = (size_t)2 * NT_LONG * 16 * LDR * sizeof(bf16_t);
+template <int NT, int NW>
+int launch_fwd_block(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+    const size_t lds = (size_t)2 * NT * 16 * LDR * sizeof(bf16_t);
     const dim3 grid((unsigned)(batch * heads));
     if (causal) {
-        SC_TRY(reserve_lds(attn_fwd_long_kernel<NT_LONG, true>, lds));
-        hipLaunchKernelGGL((attn_fwd_long_kernel<NT_LONG, true>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+        SC_TRY(reserve_lds(attn_fwd_long_kernel<NT, true, NW>, lds));
+        hipLaunchKernelGGL((attn_fwd_long_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
     } else {
-        SC_TRY(reserve_lds(attn_fwd_long_kernel<NT_LONG, false>, lds));
-        hipLaunchKernelGGL((attn_fwd_long_kernel<NT_LONG, false>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+        SC_TRY(reserve_lds(attn_fwd_long_kernel<NT, false, NW>, lds));
+        hipLaunchKernelGGL((attn_fwd_long_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+template <int NT, int NW>
+int launch_bwd_block(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+    const size_t lds = ((size_t)3 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)3 * NT * 16 * sizeof(float);
+    const dim3 grid((unsigned)(batch * heads));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_bwd_long_kernel<NT, true, NW>, lds));
+        hipLaunchKernelGGL((attn_bwd_long_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
+                           (int)width, (int)heads, 0.125f);
+    } else {
+        SC_TRY(reserve_lds(attn_bwd_long_kernel<NT, false, NW>, lds));
+        hipLaunchKernelGGL((attn_bwd_long_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
+                           (int)width, (int)heads, 0.125f);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
 
+}  // namespace
+
+// bf16, one workgroup per head, one wave per 16-row tile of the head where that fits (seq <= 64: 4 waves, <= 80: 5 waves) and
+// 4 waves striding over the tiles up to seq = 272.  The three (forward: two) LDS images are shared by the waves of a
+// workgroup: ~28 KiB per head at seq <= 64, so five workgroups = 20 waves fit a CU, where the one-wave-per-head kernels of
+// attention_mfma.hip (private images, 110 KiB per 4-wave workgroup) are held to ONE wave per SIMD by LDS capacity.
+// Returns 1 when the shape is not covered.
+int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+    if (seq > NT_LONG * 16) return 1;
+    if (seq <= 64) return launch_fwd_block<4, 4>(qkv, out, batch, seq, width, heads, causal, st);
+    if (seq <= 80) return launch_fwd_block<5, 5>(qkv, out, batch, seq, width, heads, causal, st);
+    return launch_fwd_block<NT_LONG, 4>(qkv, out, batch, seq, width, heads, causal, st);
+}
+
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                           hipStream_t st) {
     if (seq > NT_LONG * 16) return 1;
-    const size_t lds = ((size_t)3 * NT_LONG * 16 * LDR) * sizeof(bf16_t) + (size_t)3 * NT_LONG * 16 * sizeof(float);
-    const dim3 grid((unsigned)(batch * heads));
-    if (causal) {
-        SC_TRY(reserve_lds(attn_bwd_long_kernel<NT_LONG, true>, lds));
-        hipLaunchKernelGGL((attn_bwd_long_kernel<NT_LONG, true>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width,
-                           (int)heads, 0.125f);
-    } else {
-        SC_TRY(reserve_lds(attn_bwd_long_kernel<NT_LONG, false>, lds));
-        hipLaunchKernelGGL((attn_bwd_long_kernel<NT_LONG, false>), grid, dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width,
-                           (int)heads, 0.125f);
-    }
-    SC_CHECK_LAUNCH();
-    return SC_OK;
+    if (seq <= 64) return launch_bwd_block<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, st);
+    if (seq <= 80) return launch_bwd_block<5, 5>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, st);
+    return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, st);
 }

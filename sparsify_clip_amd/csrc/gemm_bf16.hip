@@ -1230,7 +1230,8 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
         p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
         const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
         static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : (e && e[0] == '2') ? 2 : 0; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant, =2: 256x128 everywhere
-        if (variant == 0 && n >= 1536 && m >= 4096) {
+        static const int big_min_n = [] { const char* e = getenv("SC_GEMM_NT_BIG_MINN"); return e ? atoi(e) : 512; }();   // A/B knob (1536: wide outputs only)
+        if (variant == 0 && n >= big_min_n && m >= 4096) {
             p.tiles_m = (int)sc_cdiv(m, B_M); p.tiles_n = (int)sc_cdiv(n, B_N);
             const unsigned gridb = (unsigned)(p.tiles_m * p.tiles_n);
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);

@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""Attention forward / backward at the step's two shapes (image: S=50 x 12 heads, text: S=77 x 8 heads, causal), HIP events."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sparsify_clip_amd import ops
+dev = "cuda:0"
+def timed(fn, reps=7):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    return sorted(ts)[len(ts) // 2]
+for name, (b, s, w, h, causal) in {"image": (1024, 50, 768, 12, False), "text": (1024, 77, 512, 8, True)}.items():
+    qkv = torch.randn(b * s, 3 * w, device=dev).to(torch.bfloat16)
+    do = torch.randn(b * s, w, device=dev).to(torch.bfloat16)
+    out = ops.attention_fwd(qkv, b, s, h, causal)
+    f = timed(lambda: ops.attention_fwd(qkv, b, s, h, causal))
+    g = timed(lambda: ops.attention_bwd(qkv, do, b, s, h, causal))
+    fb = (qkv.numel() + out.numel()) * 2; bb = (2 * qkv.numel() + do.numel()) * 2
+    print(f"attention {name:5s} S={s}: fwd {f*1e3:7.1f} us ({fb/f/1e9:6.2f} TB/s of {fb/1e6:.0f} MB)   bwd {g*1e3:7.1f} us ({bb/g/1e9:6.2f} TB/s of {bb/1e6:.0f} MB)", flush=True)
