@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_SHAPE = -2, SC_ERR_DTYPE = -3, SC_ERR_ALIGN = -4,
        SC_ERR_WORKSPACE = -5, SC_ERR_NO_DEVICE = -6 };
@@ -52,6 +52,15 @@ typedef struct sc_gemm_epilogue {
     const void* resid;        /* [M,N] added after the activation, or NULL */
     const void* dgelu_pre;    /* [M,N] activation dtype: multiply by GELU'(this), or NULL (backward of K7) */
     int64_t ld_aux;           /* leading dimension of pre_out / resid / dgelu_pre */
+    /* optional: colsum[n] = (colsum_accumulate ? colsum[n] : 0) + sum_m out[m][n] of the values as stored (the bias gradient of
+     * the layer that produced the GEMM's A operand when `out` is a pre-activation gradient, e.g. d_h = (dY W2) * GELU'(h)).
+     * Fused into the epilogue where the kernel supports it, otherwise a pass over `out`; fixed-order partial sums in colsum_ws
+     * (>= 4 * N * ceil(M / 128) bytes, or >= 4096 * N bytes for the fallback pass). */
+    float* colsum;            /* [N] fp32 or NULL */
+    void* colsum_ws;
+    uint64_t colsum_ws_bytes;
+    int32_t colsum_accumulate;
+    int32_t reserved_;
 } sc_gemm_epilogue;
 
 /* fp32 MFMA GEMM, any operand orientation: C[M,N] = op(A) * op(B).

@@ -25,7 +25,9 @@ class ScError(RuntimeError):
 class GemmEpilogue(ctypes.Structure):
     _fields_ = [("alpha", ctypes.c_float), ("beta", ctypes.c_float), ("bias", ctypes.c_void_p), ("pre_out", ctypes.c_void_p),
                 ("act", ctypes.c_int32), ("resid_dtype", ctypes.c_int32), ("resid", ctypes.c_void_p),
-                ("dgelu_pre", ctypes.c_void_p), ("ld_aux", ctypes.c_int64)]
+                ("dgelu_pre", ctypes.c_void_p), ("ld_aux", ctypes.c_int64),
+                ("colsum", ctypes.c_void_p), ("colsum_ws", ctypes.c_void_p), ("colsum_ws_bytes", ctypes.c_uint64),
+                ("colsum_accumulate", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
 _BLOCK_PTRS_1 = ["ln1_g", "ln1_b", "b_qkv", "b_o", "ln2_g", "ln2_b", "b_fc1", "b_fc2",

@@ -151,13 +151,16 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     SC_TRY(publish());
     SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
     if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));   // reads the fp32 dx_out: main stream
+    static const bool fuse_cs = [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum passes (A/B runs)
+    const bool fcs = bf && fuse_cs;
     EpiParams e = epi_plain();
     e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
+    if (fcs) {   // c_fc's bias gradient = column sums of d_h: taken in the epilogue that produces d_h (main stream, main workspace)
+        e.colsum = d->g_b_fc1; e.colsum_ws = d->ws; e.colsum_ws_bytes = d->ws_bytes; e.colsum_accumulate = acc;
+    }
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
     SC_TRY(publish());
-    static const bool fuse_cs = [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum pass (A/B runs)
-    const bool fcs = bf && fuse_cs;
-    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss, fcs ? d->g_b_fc1 : nullptr));
+    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
     if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
     // dx_mid = dx_out + LN2'(d_ln); the same kernel emits the operand copy and the out_proj bias gradient (column sums of dx_mid).

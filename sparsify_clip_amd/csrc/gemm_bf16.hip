@@ -19,6 +19,7 @@
 
 extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
                          void* stream);
+int sc_colsum_reduce(const float* partial, int nslab, int64_t n, float* out, int accumulate, hipStream_t st);
 
 namespace {
 
@@ -517,6 +518,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     if (e.bias) { bias0 = *(const f32x4*)(e.bias + nn); bias1 = *(const f32x4*)(e.bias + nn + 4); }
     __syncthreads();   // every wave is done reading the last K-tile
     float* slab = (float*)smem + wave * (64 * 68);
+    // fused column sums of the stored output (bias gradient of the producing layer): per lane 8 columns over all of its rows
+    const bool do_cs = e.cs_partial != nullptr;
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int mw = m0 + wm * 128 + h * 64;
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
                     if (e.beta != 0.f) { v0 += *(const f32x4*)cp * e.beta; v1 += *(const f32x4*)(cp + 4) * e.beta; }
                     *(f32x4*)cp = v0;
                     *(f32x4*)(cp + 4) = v1;
+                    if (do_cs) { cs0 += v0; cs1 += v1; }
                 } else {
                     uint4 u;
                     u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
@@ -574,9 +579,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
                     u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
                     u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
                     *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
+                    if (do_cs) {   // the values as stored (bf16-rounded): identical to a pass over C
+                        cs0[0] += __uint_as_float(u.x << 16); cs0[1] += __uint_as_float(u.x & 0xffff0000u);
+                        cs0[2] += __uint_as_float(u.y << 16); cs0[3] += __uint_as_float(u.y & 0xffff0000u);
+                        cs1[0] += __uint_as_float(u.z << 16); cs1[1] += __uint_as_float(u.z & 0xffff0000u);
+                        cs1[2] += __uint_as_float(u.w << 16); cs1[3] += __uint_as_float(u.w & 0xffff0000u);
+                    }
                 }
             }
           }
+        }
+    }
+    if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per (row tile, wave row)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cs0[j] += __shfl_xor(cs0[j], 8, 64);  cs1[j] += __shfl_xor(cs1[j], 8, 64);
+            cs0[j] += __shfl_xor(cs0[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64);
+            cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
+        }
+        if (lane < 8 && ncol_ok) {
+            float* dst = e.cs_partial + (int64_t)((m0 / B_M) * 2 + wm) * p.N + n;
+            *(f32x4*)dst = cs0;
+            *(f32x4*)(dst + 4) = cs1;
         }
     }
 }
@@ -1214,12 +1238,15 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     SC_REQUIRE(out_dtype == SC_BF16 || out_dtype == SC_F32, SC_ERR_DTYPE, "sc_gemm_bf16_nt: bad out dtype");
     SC_REQUIRE(!(epi.pre_out || epi.resid || epi.dgelu_pre) || epi.ld_aux % 4 == 0, SC_ERR_SHAPE, "sc_gemm_bf16_nt: ld_aux must be a multiple of 4");
     SC_REQUIRE(epi.beta == 0.f || out_dtype == SC_F32, SC_ERR_ARG, "sc_gemm_bf16_nt: beta needs an fp32 C");
+    SC_REQUIRE(!epi.colsum || (epi.colsum_ws && n % 8 == 0), SC_ERR_ARG, "sc_gemm_bf16_nt: colsum needs a workspace and N % 8 == 0");
     GemmBf16Params p;
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)k;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.splits = 1; p.k_per_split = 0; p.partial = nullptr;
     p.epi = epi;
+    p.epi.cs_partial = nullptr;
+    bool cs_fused = false;
     static const bool small_tile = [] { const char* e = getenv("SC_GEMM_NT"); return e && e[0] == '1'; }();   // SC_GEMM_NT=128: A/B runs
     if (small_tile || n % 8 != 0 || ldc % 8 != 0 || (epi.ld_aux % 8 != 0 && (epi.pre_out || epi.resid || epi.dgelu_pre))) {
         p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
@@ -1234,6 +1261,10 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
         if (variant == 0 && n >= big_min_n && m >= 4096) {
             p.tiles_m = (int)sc_cdiv(m, B_M); p.tiles_n = (int)sc_cdiv(n, B_N);
             const unsigned gridb = (unsigned)(p.tiles_m * p.tiles_n);
+            if (epi.colsum && epi.colsum_ws_bytes >= (size_t)2 * p.tiles_m * n * sizeof(float) && sc_aligned(epi.colsum_ws, 16)) {
+                p.epi.cs_partial = (float*)epi.colsum_ws;   // [2 * tiles_m][N]; rows past M contribute nothing, every slot is written
+                cs_fused = true;
+            }
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
         } else if (variant == 3) {
@@ -1245,6 +1276,10 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
         }
     }
     SC_CHECK_LAUNCH();
+    if (epi.colsum) {
+        if (cs_fused) return sc_colsum_reduce((const float*)epi.colsum_ws, 2 * p.tiles_m, n, epi.colsum, epi.colsum_accumulate, stream);
+        return sc_colsum(c, out_dtype, m, n, ldc, epi.colsum, epi.colsum_accumulate, epi.colsum_ws, epi.colsum_ws_bytes, (void*)stream);
+    }
     return SC_OK;
 }
 

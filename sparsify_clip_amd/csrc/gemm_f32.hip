@@ -9,6 +9,9 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
+                         void* stream);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -170,5 +173,8 @@ extern "C" int sc_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
                            const float* b, int64_t ldb, float* c, int64_t ldc, const sc_gemm_epilogue* e, void* stream) {
     EpiParams epi;
     SC_TRY(epi_from_abi(e, SC_F32, epi));
-    return sc_gemm_f32_launch(trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, epi, (hipStream_t)stream);
+    SC_TRY(sc_gemm_f32_launch(trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, epi, (hipStream_t)stream));
+    if (epi.colsum)   // the fp32 kernel has no fused column sums: a pass over the stored C
+        return sc_colsum(c, SC_F32, m, n, ldc, epi.colsum, epi.colsum_accumulate, epi.colsum_ws, epi.colsum_ws_bytes, stream);
+    return SC_OK;
 }

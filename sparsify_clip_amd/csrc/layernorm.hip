@@ -221,6 +221,14 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
     return SC_OK;
 }
 
+// out[n] (+)= sum over nslab partial rows [nslab][n] (fixed order); second stage of sc_colsum, also used by the GEMM's fused column sums
+int sc_colsum_reduce(const float* partial, int nslab, int64_t n, float* out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 16)), dim3(256), 0, st, partial, nslab, 1, (int)n, out, (float*)nullptr,
+                       (float*)nullptr, accumulate);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
 extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
                          void* stream) {
     SC_REQUIRE(x && out && rows > 0 && n > 0, SC_ERR_ARG, "sc_colsum: bad argument");

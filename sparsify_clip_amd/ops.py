@@ -24,7 +24,9 @@ def _workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
     return buf
 
 
-def make_epilogue(alpha=1.0, beta=0.0, bias=None, pre_out=None, act=0, resid=None, dgelu_pre=None, ld_aux=0):
+def make_epilogue(alpha=1.0, beta=0.0, bias=None, pre_out=None, act=0, resid=None, dgelu_pre=None, ld_aux=0, colsum=None,
+                  colsum_accumulate=False, rows=None):
+    """colsum ([N] fp32): also receive the column sums of the stored output; `rows` (the GEMM's M) sizes the partial-sum workspace."""
     e = GemmEpilogue()
     e.alpha, e.beta, e.act = float(alpha), float(beta), int(act)
     e.bias = bias.data_ptr() if bias is not None else None
@@ -33,7 +35,14 @@ def make_epilogue(alpha=1.0, beta=0.0, bias=None, pre_out=None, act=0, resid=Non
     e.resid_dtype = sc_dtype(resid.dtype) if resid is not None else SC_F32
     e.dgelu_pre = dgelu_pre.data_ptr() if dgelu_pre is not None else None
     e.ld_aux = int(ld_aux)
-    e._keepalive = (bias, pre_out, resid, dgelu_pre)   # the struct only holds raw pointers
+    ws = None
+    if colsum is not None:
+        if rows is None:
+            raise ScError("make_epilogue: colsum needs rows (the GEMM's M)")
+        n = colsum.numel()
+        ws = torch.empty(max(4096 * n, ((rows + 127) // 128) * n) * 4, dtype=torch.uint8, device=colsum.device)
+        e.colsum, e.colsum_ws, e.colsum_ws_bytes, e.colsum_accumulate = colsum.data_ptr(), ws.data_ptr(), ws.numel(), int(bool(colsum_accumulate))
+    e._keepalive = (bias, pre_out, resid, dgelu_pre, colsum, ws)   # the struct only holds raw pointers
     return e
 
 

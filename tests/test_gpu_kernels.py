@@ -128,6 +128,27 @@ def test_gemm_bf16_epilogue_gelu_series_accuracy(ops):
     assert_close(got, gelu_grad64(x.double()), 0, 3e-5, "GELU' series")
 
 
+@pytest.mark.parametrize("m,n,k", [(4100, 1544, 192), (8192, 768, 128), (300, 192, 128)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_nt_epilogue_colsum(ops, m, n, k, out_dtype):
+    """Column sums of the stored output taken by the epilogue (256x256 kernel: fused; small problems: fallback pass): equal to
+    summing the stored C, with and without accumulation, and the GEMM result itself is unchanged."""
+    a, w = rnd(m, k, seed=41, dtype=torch.bfloat16).to(DEV), rnd(n, k, seed=42, scale=0.1, dtype=torch.bfloat16).to(DEV)
+    pre = rnd(m, n, seed=43, dtype=torch.bfloat16).to(DEV)
+    want_c = ops.gemm_bf16_nt(a, w, out_dtype=out_dtype, epi=ops.make_epilogue(dgelu_pre=pre, ld_aux=n))
+    cs = torch.full((n,), 5.0, device=DEV)
+    got_c = ops.gemm_bf16_nt(a, w, out_dtype=out_dtype, epi=ops.make_epilogue(dgelu_pre=pre, ld_aux=n, colsum=cs, rows=m))
+    assert torch.equal(got_c, want_c), "the fused column sums must not change C"
+    want_s = want_c.double().sum(0)
+    assert_close(cs, want_s, 1e-5, 2e-4 * np.sqrt(m), "epilogue colsum")
+    cs2 = torch.full((n,), 5.0, device=DEV)
+    ops.gemm_bf16_nt(a, w, out_dtype=out_dtype, epi=ops.make_epilogue(dgelu_pre=pre, ld_aux=n, colsum=cs2, colsum_accumulate=True, rows=m))
+    assert_close(cs2, want_s + 5.0, 1e-5, 2e-4 * np.sqrt(m), "epilogue colsum, accumulate")
+    cs3 = torch.empty(n, device=DEV)
+    ops.gemm_bf16_nt(a, w, out_dtype=out_dtype, epi=ops.make_epilogue(dgelu_pre=pre, ld_aux=n, colsum=cs3, rows=m))
+    assert torch.equal(cs, cs3)
+
+
 def test_gemm_bf16_nt_asymmetric_identity(ops):
     """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)."""
     n, k = 256, 128
