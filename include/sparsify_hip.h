@@ -148,6 +148,12 @@ int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64
                      int causal, void* stream);
 int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq,
                      int64_t width, int64_t heads, int causal, void* stream);
+/* Same, plus colsum[n] (+)= column sums of d_qkv over all rows: the in_proj bias gradient (autograd of nn.MultiheadAttention's
+ * in_proj under reference sparsify_clip.py:965).  The bf16 MFMA kernels accumulate them while they hold dq / dk / dv in
+ * registers ([batch][3*width] fp32 partials in ws, >= 4*batch*3*width bytes, then a fixed-order reduce); other paths run a
+ * pass over d_qkv (ws >= 4096*3*width*4 bytes). */
+int sc_attention_bwd_colsum(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
+                            int64_t heads, int causal, float* colsum, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 1024*n floats */
 int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate,
               void* ws, size_t ws_bytes, void* stream);

@@ -9,10 +9,14 @@
 
 int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
 int sc_attention_mfma_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                          hipStream_t st);
+                          float* cs_part, hipStream_t st);
 int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                          hipStream_t st);
+                          float* cs_part, hipStream_t st);
+
+int sc_colsum_reduce(const float* partial, int nslab, int64_t n, float* out, int accumulate, hipStream_t st);
+extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
+                         void* stream);
 
 namespace {
 
@@ -205,15 +209,21 @@ extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t b
     return SC_OK;
 }
 
-extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
-                                int64_t heads, int causal, void* stream) {
+namespace {
+// cs_part != null: the MFMA kernels also write [batch][3 W] column sums of d_qkv per image; *cs_done tells whether they did
+int attention_bwd_impl(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                       float* cs_part, bool* cs_done, void* stream) {
+    if (cs_done) *cs_done = false;
     SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
         // backward: one workgroup per head wins at seq <= 64 (262 vs 303 us, S = 50), one wave per head at 64 < seq <= 80 (286 vs 341 us, S = 77)
-        int rc = (wave_per_head() || seq > 64) ? sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream) : 1;
-        if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, (hipStream_t)stream);
-        if (rc != 1) return rc;
+        int rc = (wave_per_head() || seq > 64) ? sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream) : 1;
+        if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream);
+        if (rc != 1) {
+            if (cs_done) *cs_done = rc == SC_OK && cs_part != nullptr;
+            return rc;
+        }
     }
     const size_t lds = ((size_t)4 * seq * HDP + 2 * seq * (seq + 1)) * sizeof(float);
     SC_REQUIRE(lds <= 160 * 1024, SC_ERR_SHAPE, "sc_attention_bwd: sequence length %lld needs %zu bytes of LDS (> 160 KiB)", (long long)seq, lds);
@@ -230,4 +240,21 @@ extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv,
 #undef LAUNCH_BWD
     SC_CHECK_LAUNCH();
     return SC_OK;
+}
+}  // namespace
+
+extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
+                                int64_t heads, int causal, void* stream) {
+    return attention_bwd_impl(qkv, d_out, d_qkv, dtype, batch, seq, width, heads, causal, nullptr, nullptr, stream);
+}
+
+extern "C" int sc_attention_bwd_colsum(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
+                                       int64_t heads, int causal, float* colsum, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(colsum && ws, SC_ERR_ARG, "sc_attention_bwd_colsum: null colsum / workspace");
+    const int64_t n = 3 * width;
+    float* part = (ws_bytes >= (size_t)batch * n * sizeof(float) && sc_aligned(ws, 16)) ? (float*)ws : nullptr;
+    bool fused = false;
+    SC_TRY(attention_bwd_impl(qkv, d_out, d_qkv, dtype, batch, seq, width, heads, causal, part, &fused, stream));
+    if (fused) return sc_colsum_reduce(part, (int)batch, n, colsum, accumulate, (hipStream_t)stream);
+    return sc_colsum(d_qkv, dtype, batch * seq, n, n, colsum, accumulate, ws, ws_bytes, stream);   // fp32 / VALU path: a pass over d_qkv
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
 // ------------------------------------------------------------------------------------------------ backward
 template <int NT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
-                                                            float scale) {
+                                                            float scale, float* cs_part /* [batch][3 W] column sums of d_qkv per image, or null */) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;                 // elements per LDS image
@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
         for (int ks = 0; ks < 2; ++ks) Vf[jt][ks] = row_frag_global(vb, ld, jt, ks, lane, S);
 
     const int n_t = (S + 15) >> 4;
+    f32x4 csq[4], csk[4], csv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) csq[dt] = csk[dt] = csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---------------- pass 1: lane = query row i.  P, dS in registers -> dQ ; row statistics -> LDS
     for (int it = 0; it < n_t; ++it) {
         const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
         }
+        if (cs_part) cs_add(csq, dq, i < S);
     }
     // statistics rows of the padding tile (only read when NT is odd and the last k-step is half empty: never) stay untouched
     // ---------------- pass 2: lane = key row j.  P^T, dS^T products -> dV, dK
@@ -256,6 +260,19 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
                 io<bf16_t>::st4(dqb + (int64_t)j * ld + 2 * W + 16 * dt + 4 * g, dv[dt]);
             }
         }
+        if (cs_part) { cs_add(csk, dk, j < S); cs_add(csv, dv, j < S); }
+    }
+    if (cs_part) {   // this wave is the only producer of its head's 192 columns for image b
+        cs_rows(csq); cs_rows(csk); cs_rows(csv);
+        if (c16 == 0) {
+            float* dst = cs_part + (int64_t)b * 3 * W + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(f32x4*)(dst + 16 * dt) = csq[dt];
+                *(f32x4*)(dst + W + 16 * dt) = csk[dt];
+                *(f32x4*)(dst + 2 * W + 16 * dt) = csv[dt];
+            }
+        }
     }
 }
 
@@ -284,15 +301,15 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total, b
 }
 
 template <int NT>
-int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, hipStream_t st) {
+int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
     const size_t lds = (size_t)4 * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
     const dim3 grid((unsigned)sc_cdiv(total, 4));
     if (causal) {
         SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f);
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     } else {
         SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f);
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -309,9 +326,9 @@ int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq
     return launch_fwd<5>((const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, total, causal != 0, st);
 }
 int sc_attention_mfma_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                          hipStream_t st) {
+                          float* cs_part, hipStream_t st) {
     if (seq > 80) return 1;
     const int total = (int)(batch * heads);
-    if (seq <= 64) return launch_bwd<4>((const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width, (int)heads, total, causal != 0, st);
-    return launch_bwd<5>((const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width, (int)heads, total, causal != 0, st);
+    if (seq <= 64) return launch_bwd<4>((const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width, (int)heads, total, causal != 0, cs_part, st);
+    return launch_bwd<5>((const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width, (int)heads, total, causal != 0, cs_part, st);
 }

@@ -76,3 +76,23 @@ static __device__ __forceinline__ void stage_head_block(bf16_t* img, const bf16_
 }
 
 }  // namespace attn
+
+// Fused in_proj bias gradient: running column sums of the dq / dk / dv tiles a wave produces (values as stored, i.e. bf16-rounded),
+// reduced over the 16 row lanes at the end.  acc[dt][r] belongs to column 16 dt + 4 (lane >> 4) + r of the head.
+__device__ __forceinline__ void cs_add(f32x4 (&acc)[4], const f32x4 (&v)[4], bool live) {
+    if (!live) return;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[dt][r] += bf16_to_f32(f32_to_bf16(v[dt][r]));
+}
+__device__ __forceinline__ void cs_rows(f32x4 (&acc)[4]) {   // sum over lane bits 0..3 (the 16 rows of a tile), fixed order
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = acc[dt][r];
+            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+            acc[dt][r] = x;
+        }
+}

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const bf16_t* qk
 }
 
 template <int NT, bool CAUSAL, int NW>
-__global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale) {
+__global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale,
+                                                                                      float* cs_part /* [batch][3 W] or null */) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;
@@ -109,6 +110,9 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
     const int g = lane >> 4, c16 = lane & 15;
     const int n_t = (S + 15) >> 4;
 
+    f32x4 csq[4], csk[4], csv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) csq[dt] = csk[dt] = csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---------------- pass 1: lane = query row i
     for (int it = wave; it < n_t; it += NW) {
         const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
         }
+        if (cs_part) cs_add(csq, dq, i < S);
     }
     // tiles of padding queries (none when n_t == NT) must read as "no contribution" in pass 2
     for (int i = n_t * 16 + tid; i < NT * 16; i += 64 * NW) st_m[i] = st_il[i] = st_dl[i] = 0.f;
@@ -234,6 +239,27 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
                 io<bf16_t>::st4(dqb + (int64_t)j * ld + 2 * W + 16 * dt + 4 * g, dv[dt]);
             }
         }
+        if (cs_part) { cs_add(csk, dk, j < S); cs_add(csv, dv, j < S); }
+    }
+    if (cs_part) {   // per-wave sums over its tiles -> LDS -> the head's 192 columns for image b, waves added in a fixed order
+        cs_rows(csq); cs_rows(csk); cs_rows(csv);
+        __syncthreads();                       // the LDS images are dead
+        float* red = (float*)lds_bl;           // [NW][192]
+        if (c16 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(f32x4*)(red + wave * 192 + 16 * dt + 4 * g) = csq[dt];
+                *(f32x4*)(red + wave * 192 + 64 + 16 * dt + 4 * g) = csk[dt];
+                *(f32x4*)(red + wave * 192 + 128 + 16 * dt + 4 * g) = csv[dt];
+            }
+        }
+        __syncthreads();
+        if (tid < 192) {
+            float v = red[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) v += red[w2 * 192 + tid];
+            cs_part[(int64_t)b * 3 * W + (tid >> 6) * W + h * HD + (tid & 63)] = v;
+        }
     }
 }
 
@@ -263,17 +289,18 @@ int launch_fwd_block(const void* qkv, void* out, int64_t batch, int64_t seq, int
     return SC_OK;
 }
 template <int NT, int NW>
-int launch_bwd_block(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+int launch_bwd_block(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, float* cs_part,
+                     hipStream_t st) {
     const size_t lds = ((size_t)3 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)3 * NT * 16 * sizeof(float);
     const dim3 grid((unsigned)(batch * heads));
     if (causal) {
         SC_TRY(reserve_lds(attn_bwd_long_kernel<NT, true, NW>, lds));
         hipLaunchKernelGGL((attn_bwd_long_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
-                           (int)width, (int)heads, 0.125f);
+                           (int)width, (int)heads, 0.125f, cs_part);
     } else {
         SC_TRY(reserve_lds(attn_bwd_long_kernel<NT, false, NW>, lds));
         hipLaunchKernelGGL((attn_bwd_long_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
-                           (int)width, (int)heads, 0.125f);
+                           (int)width, (int)heads, 0.125f, cs_part);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -294,9 +321,9 @@ int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq
 }
 
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                          hipStream_t st) {
+                          float* cs_part, hipStream_t st) {
     if (seq > NT_LONG * 16) return 1;
-    if (seq <= 64) return launch_bwd_block<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, st);
-    if (seq <= 80) return launch_bwd_block<5, 5>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, st);
-    return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, st);
+    if (seq <= 64) return launch_bwd_block<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
+    if (seq <= 80) return launch_bwd_block<5, 5>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
+    return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
 }

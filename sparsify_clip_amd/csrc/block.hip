@@ -173,9 +173,11 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     SC_TRY(publish());
     SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
-    SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
+    // in_proj's bias gradient = column sums of d_qkv: taken by the attention backward while dq / dk / dv are in registers
+    if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
+    else SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss, fcs ? d->g_b_qkv : nullptr));
+    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));
     if (!fcs) SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
     // dx_in = dx_mid + LN1'(d_ln)

@@ -136,28 +136,43 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
     }
 }
 
-// out[which][col] (+)= sum_b partial[b][which][col]     (nwhich slabs of `width` columns per block)
-// 16 columns x 16 row groups per workgroup (many small workgroups: the slabs are L2-resident and this kernel is latency-
-// bound); the 16 group sums are combined in a fixed order
+// out[which][col] (+)= sum_b partial[b][which][col]     (nwhich slabs of `width` columns per block; width % 4 == 0)
+// A workgroup owns 32 consecutive columns of the flattened [nwhich * width] row: 8 threads x 16 bytes across, 32 row groups down;
+// every load is a 16-byte piece of a 128-byte run, the 32 group sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1,
                                                              float* out2, int accumulate) {
-    __shared__ float sm[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + tx;
-    const bool live = i < nwhich * width;
-    const int which = live ? i / width : 0, col = live ? i - which * width : 0;
-    float s = 0.f;
-    if (live)
-        for (int b = ty; b < nblocks; b += 16) s += partial[((int64_t)b * nwhich + which) * width + col];
+    __shared__ f32x4 sm[32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int total = nwhich * width;
+    const int i = (blockIdx.x * 8 + tx) * 4;
+    const bool live = i < total;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float* p = partial + i;
+        int b = ty;
+        for (; b + 96 < nblocks; b += 128) {   // four independent loads in flight per thread
+            const f32x4 v0 = *(const f32x4*)(p + (int64_t)b * total), v1 = *(const f32x4*)(p + (int64_t)(b + 32) * total);
+            const f32x4 v2 = *(const f32x4*)(p + (int64_t)(b + 64) * total), v3 = *(const f32x4*)(p + (int64_t)(b + 96) * total);
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nblocks; b += 32) s += *(const f32x4*)(p + (int64_t)b * total);
+    }
     sm[ty][tx] = s;
     __syncthreads();
     if (ty != 0 || !live) return;
-    s = 0.f;
+    s = sm[0][tx];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += sm[k][tx];
+    for (int k = 1; k < 32; ++k) s += sm[k][tx];
+    const int which = i / width, col = i - which * width;
     float* out = which == 0 ? out0 : (which == 1 ? out1 : out2);
     if (!out) return;
-    out[col] = accumulate ? out[col] + s : s;
+    if ((((size_t)(out + col)) & 15) == 0) {
+        f32x4* o = (f32x4*)(out + col);
+        *o = accumulate ? *o + s : s;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[col + e] = accumulate ? out[col + e] + s[e] : s[e];
+    }
 }
 
 // column sums of x [rows, n]: thread = 4 consecutive columns, blockIdx.y = row slab
@@ -215,7 +230,7 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
 #undef LN_BWD_C
 #undef LN_BWD
     if (dgamma || dbeta || dx_colsum)
-        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 16)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 32)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,
                            dbeta, dx_colsum, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -223,7 +238,7 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
 
 // out[n] (+)= sum over nslab partial rows [nslab][n] (fixed order); second stage of sc_colsum, also used by the GEMM's fused column sums
 int sc_colsum_reduce(const float* partial, int nslab, int64_t n, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 16)), dim3(256), 0, st, partial, nslab, 1, (int)n, out, (float*)nullptr,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 32)), dim3(256), 0, st, partial, nslab, 1, (int)n, out, (float*)nullptr,
                        (float*)nullptr, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -245,7 +260,7 @@ extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int6
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (int)n, ld, rpb, (float*)ws);
     else
         return sc_set_error(SC_ERR_DTYPE, "sc_colsum: bad dtype %d", dtype);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 32)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
                        (float*)nullptr, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;

@@ -217,10 +217,16 @@ def attention_fwd(qkv, batch, seq, heads, causal):
     return out
 
 
-def attention_bwd(qkv, d_out, batch, seq, heads, causal):
+def attention_bwd(qkv, d_out, batch, seq, heads, causal, colsum_out=None, colsum_accumulate=False):
+    """d_qkv; with colsum_out ([3*width] fp32) also the column sums of d_qkv over all rows (the in_proj bias gradient)."""
     w = qkv.shape[1] // 3
     d_qkv = torch.empty_like(qkv)
-    LIB.call("sc_attention_bwd", ptr(qkv), ptr(d_out), ptr(d_qkv), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
+    if colsum_out is None:
+        LIB.call("sc_attention_bwd", ptr(qkv), ptr(d_out), ptr(d_qkv), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
+        return d_qkv
+    ws = _workspace(max(batch, 4096) * 3 * w * 4, qkv.device)
+    LIB.call("sc_attention_bwd_colsum", ptr(qkv), ptr(d_out), ptr(d_qkv), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), ptr(colsum_out),
+             int(bool(colsum_accumulate)), ptr(ws), ws.numel(), stream_ptr())
     return d_qkv
 
 

@@ -418,6 +418,26 @@ def test_attention(ops, dtype, seq, heads, causal):
         assert_close(d_qkv, q64.grad, *tolb, "attention bwd")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (257, 2, False)])
+def test_attention_bwd_fused_colsum(ops, dtype, seq, heads, causal):
+    """in_proj bias gradient from the attention backward: equal to summing the stored d_qkv (bit-identical d_qkv, sums within fp32
+    reassociation), on the one-wave and one-workgroup MFMA kernels and on the fallback pass of the fp32 path."""
+    if seq > 128 and dtype == torch.float32:
+        pytest.skip("fp32 attention: S <= 128")
+    batch, w = 5, heads * 64
+    qkv = rnd(batch * seq, 3 * w, seed=61).to(dtype).to(DEV)
+    d_out = rnd(batch * seq, w, seed=62).to(dtype).to(DEV)
+    want = ops.attention_bwd(qkv, d_out, batch, seq, heads, causal)
+    cs = torch.full((3 * w,), 2.0, device=DEV)
+    got = ops.attention_bwd(qkv, d_out, batch, seq, heads, causal, colsum_out=cs)
+    assert torch.equal(got, want)
+    assert_close(cs, want.double().sum(0), 1e-5, 1e-4, "attention bwd colsum")
+    cs2 = torch.full((3 * w,), 2.0, device=DEV)
+    ops.attention_bwd(qkv, d_out, batch, seq, heads, causal, colsum_out=cs2, colsum_accumulate=True)
+    assert_close(cs2, want.double().sum(0) + 2.0, 1e-5, 1e-4, "attention bwd colsum, accumulate")
+
+
 def test_colsum_cast_transpose(ops):
     x = rnd(1000, 2304, seed=61)
     assert_close(ops.colsum(x.to(DEV)), x.double().sum(0), 1e-5, 1e-3, "colsum f32")
