@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
         float m = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
+            if (CAUSAL && jt > it) {   // key tile entirely in the future of this query tile: p = dS = 0, no work (wave-uniform)
+                sc[jt] = dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
             a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
             a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
@@ -165,28 +169,34 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
         m = group_max(m);
         float l = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            if (CAUSAL && jt > it) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __expf(sc[jt][r] - m);
                 sc[jt][r] = p;
                 l += p;
             }
+        }
         l = group_sum(l);
         const float inv = 1.0f / l;
         float delta = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            if (CAUSAL && jt > it) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sc[jt][r] *= inv;
                 delta += sc[jt][r] * dp[jt][r];
             }
+        }
         delta = group_sum(delta);
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            if (CAUSAL && jt > it) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[jt][r] = sc[jt][r] * (dp[jt][r] - delta) * scale;   // dS (0 where p = 0)
+        }
         if (g == 0) {
             const bool live = i < S;
             st_m[i] = live ? m : 0.f;
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            if (CAUSAL && 2 * s > it) continue;   // both key tiles of this k-step are masked out
             const bf16x8 dsf = pack_frag(sc[2 * s], sc[2 * s + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -227,7 +238,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
             for (int u = 0; u < 2; ++u) {
                 pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int it = 2 * s + u;
-                if (ODD && it >= NT) continue;   // compile-time: the empty half of the last k-step
+                if (ODD && it >= NT) continue;
+                if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0   // compile-time: the empty half of the last k-step
                 f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
                 a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
                 a = MFMA16(row_frag_lds(Qs, it, 1, lane), k1, a);
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
                     dst[u][r] = p * (d[r] - dl[r]) * scale;
                 }
             }
+            if (CAUSAL && 2 * s + 1 < jt) continue;
             const bf16x8 pf = pack_frag(pt[0], pt[1]), dsf = pack_frag(dst[0], dst[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {

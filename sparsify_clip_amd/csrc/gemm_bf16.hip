@@ -444,9 +444,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
         ga[q] = p.A + (int64_t)min(m0 + wave * 32 + q * 8 + srow, p.M - 1) * p.lda + schunk * 8;
         gb[q] = p.B + (int64_t)min(n0 + wave * 32 + q * 8 + srow, p.N - 1) * p.ldb + schunk * 8;
     }
-    // reserves a0..a127 in the kernel descriptor (the compiler allocates what it sees clobbered) and clears them
+    // reserves a0..a127 in the kernel descriptor (the compiler allocates what it sees clobbered)
     asm volatile("" ::: SC_ACC_AGPRS);
-    ntb_zero<0>();
 
     const int nk = p.K / KSTEP;
     const int frow = lane & 15, fq = lane >> 4;
@@ -485,10 +484,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     } while (0)
 
     bf16x8 a[8], b0[4], b1[4];
+    // both stages are free at the start: K-tile 1 is requested together with K-tile 0 (8 LDS-DMA instructions per wave and stage),
+    // the accumulators are cleared under the first latency, and only K-tile 0 is waited for
     NTB_STAGE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     if (nk > 1) NTB_STAGE(1, 1);
+    ntb_zero<0>();
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     ntb_read<0>(b0[0], fb00); ntb_read<2048>(b0[1], fb00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(b0[3], fb00);
     ntb_read<0>(a[0], fa00); ntb_read<2048>(a[1], fa00); ntb_read<4096>(a[2], fa00); ntb_read<6144>(a[3], fa00);
     ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
@@ -1103,7 +1106,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(GemmBf16Params
     const int64_t a_step = (int64_t)KSTEP * p.lda * 2, b_step = (int64_t)KSTEP * p.ldb * 2;   // bytes per K-tile
 
     asm volatile("" ::: SC_ACC_AGPRS);   // reserve the accumulator AGPRs in the kernel descriptor
-    ntb_zero<0>();
 
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
@@ -1144,10 +1146,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(GemmBf16Params
     } while (0)
 
     i32x4 a[8], b0[4], b1[4];
-    TNB_STAGE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    TNB_STAGE(0, 0);   // as in the NT kernel: both stages requested up front, accumulators cleared under the latency
     if (nk > 1) TNB_STAGE(1, 1);
+    ntb_zero<0>();
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     b0[0] = tnb_read<0, 0>(bb0); b0[1] = tnb_read<0, 32>(bb0); b0[2] = tnb_read<0, 64>(bb0); b0[3] = tnb_read<0, 96>(bb0);
     a[0] = tnb_read<0, 0>(ab0); a[1] = tnb_read<0, 32>(ab0); a[2] = tnb_read<0, 64>(ab0); a[3] = tnb_read<0, 96>(ab0);
     a[4] = tnb_read<0, 128>(ab0); a[5] = tnb_read<0, 160>(ab0); a[6] = tnb_read<0, 192>(ab0); a[7] = tnb_read<0, 224>(ab0);

@@ -93,6 +93,7 @@ class ClipModel:
         self._grads_fresh = True   # next backward overwrites (True) or accumulates (False)
         self.comm = None      # optional data-parallel hook (dist.GradSync)
         self._scratch = {}
+        self._aux_stream, self.wt_ready = None, None
         self._side = None      # side stream of the weight-gradient GEMMs (bf16 path)
         self.init_parameters(seed)
 
@@ -246,12 +247,32 @@ class ClipModel:
         """The next backward overwrites the gradient buffer instead of accumulating (saves a 605 MB memset)."""
         self._grads_fresh = True
 
-    def refresh_shadows(self, full=False):
-        """bf16 mode: rebuild the [in,out] weight copies (and, if `full`, the bf16 shadow itself) from the masters."""
+    def refresh_shadows(self, full=False, overlap=False):
+        """bf16 mode: rebuild the [in,out] weight copies (and, if `full`, the bf16 shadow itself) from the masters.
+        `overlap`: the ~100 small transposes are only read by the NEXT backward pass, so they go to an auxiliary stream (ordered
+        behind everything enqueued so far) and run under the next forward pass; `_blocks_bwd` and the next optimiser step wait
+        for `wt_ready`."""
         if self.flat_bf16 is None:
             return
         if full:
             ops.cast_bf16(self.flat, self.flat_bf16)
+        if overlap and self.device.type == "cuda":
+            if self._aux_stream is None:
+                self._aux_stream = torch.cuda.Stream(device=self.device)
+            self._aux_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._aux_stream):
+                self._rebuild_wt()
+                self.wt_ready = torch.cuda.Event()
+                self.wt_ready.record(self._aux_stream)
+            return
+        self._rebuild_wt()
+
+    def wait_wt(self):
+        """Order the current stream behind the last overlapped rebuild of the [in,out] weight copies."""
+        if self.wt_ready is not None:
+            torch.cuda.current_stream().wait_event(self.wt_ready)
+
+    def _rebuild_wt(self):
         for tower in (self.visual, self.text):
             for i in range(tower.layers):
                 for k in GEMM_WEIGHTS:
@@ -364,6 +385,7 @@ class ClipModel:
                     self.comm.bucket_ready(f"{tower.prefix}{i}.")
             return dx
         main = torch.cuda.current_stream()
+        self.wait_wt()
         if self._side is None:
             self._side = {}
         if tower.kind not in self._side:
@@ -462,10 +484,23 @@ class ClipModel:
         ops.text_embed_fwd(tokens, self.param("token_embedding.weight"), self.param("positional_embedding"), out=b["x"][0])
         self._blocks_fwd(tw)
         b["eot"] = ops.argmax_tokens(tokens)
+        if self.training:   # bookkeeping of the backward pass, done here so that it runs under the forward GEMMs instead of at the tail of the step
+            b["sorted_keys"], b["sort_order"] = self._token_sort(tokens, b["eot"], tw.seq)
+        else:
+            b.pop("sorted_keys", None)
         b["pooled"] = ops.pool_gather(b["x"][-1], b["eot"], batch, tw.seq)
         b["pooled_ln"], b["post_mean"], b["post_rstd"] = ops.layernorm_fwd(b["pooled"], self.param("ln_final.weight"), self.param("ln_final.bias"),
                                                                            torch.float32)
         return ops.gemm_f32(b["pooled_ln"], self.param("text_projection"))
+
+    def _token_sort(self, tokens, eot, seq):
+        """Sorted token ids + permutation for the token-embedding scatter-add.  Positions after EOT carry an exactly-zero gradient
+        under the causal mask and get the key `vocab` (sorts to the end, ignored by the scatter kernel); no host sync (a
+        .nonzero() would stall the enqueue of the other tower)."""
+        pos_idx = torch.arange(seq, device=self.device, dtype=torch.int32)
+        active = pos_idx[None, :] <= eot[:, None]
+        keys = torch.where(active, tokens, torch.full_like(tokens, self.cfg["vocab"])).reshape(-1)
+        return torch.sort(keys, stable=True)
 
     def text_backward(self, d_emb):
         tw, b = self.text, self.text.bufs
@@ -482,15 +517,11 @@ class ClipModel:
         dx.zero_()
         ops.pool_scatter(d_pooled, b["eot"], batch, tw.seq, dx)
         self._blocks_bwd(tw, dx, acc)
-        # token-embedding scatter-add in a fixed order: positions after EOT carry an exactly-zero gradient under the
-        # causal mask and are left out; the index sort is bookkeeping (torch), the fp32 sums are the HIP kernel's.
-        # No host sync here (a .nonzero() would stall the enqueue of the other tower): inactive positions get the key `vocab`,
-        # sort to the end, and the scatter kernel ignores keys outside [0, vocab).
-        tokens = b["tokens"]
-        pos_idx = torch.arange(tw.seq, device=self.device, dtype=torch.int32)
-        active = pos_idx[None, :] <= b["eot"][:, None]
-        keys = torch.where(active, tokens, torch.full_like(tokens, self.cfg["vocab"])).reshape(-1)
-        st, order = torch.sort(keys, stable=True)
+        # token-embedding scatter-add in a fixed order (the index sort is bookkeeping done in text_forward, the fp32 sums are the
+        # HIP kernel's)
+        if "sorted_keys" not in b:   # forward ran in eval mode
+            b["sorted_keys"], b["sort_order"] = self._token_sort(b["tokens"], b["eot"], tw.seq)
+        st, order = b["sorted_keys"], b["sort_order"]
         ops.text_embed_bwd(dx, st, order, batch, tw.seq, self.grad("token_embedding.weight"), self.grad("positional_embedding"), acc)
         if self.comm is not None:
             self.comm.bucket_ready("text.stem")

@@ -41,9 +41,10 @@ class AdamW(torch.optim.Optimizer):
         self.steps += 1
         m = self.model
         shadow = m.flat_bf16[: m.n_trainable] if m.flat_bf16 is not None else None
+        m.wait_wt()   # the previous step's overlapped transposes read the masters this step overwrites
         ops.adamw_step(self.trainable, m.flat_grad[: m.n_trainable], self.m, self.v, shadow, g0["lr"], g0["betas"][0], g0["betas"][1],
                        g0["eps"], g0["weight_decay"], self.steps)
-        m.refresh_shadows(full=False)
+        m.refresh_shadows(full=False, overlap=True)
         # scalar extras (the learnable temperature): same kernel on a 1-element buffer; skipped when no gradient arrived,
         # exactly as torch's AdamW skips parameters whose .grad is None
         for g in self.param_groups[1:]:
