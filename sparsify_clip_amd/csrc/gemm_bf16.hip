@@ -1251,6 +1251,7 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     p.epi = epi;
     p.epi.cs_partial = nullptr;
     bool cs_fused = false;
+    int64_t cs_rows_done = 0;   // rows whose column sums the fused path covers
     static const bool small_tile = [] { const char* e = getenv("SC_GEMM_NT"); return e && e[0] == '1'; }();   // SC_GEMM_NT=128: A/B runs
     if (small_tile || n % 8 != 0 || ldc % 8 != 0 || (epi.ld_aux % 8 != 0 && (epi.pre_out || epi.resid || epi.dgelu_pre))) {
         p.tiles_m = (int)sc_cdiv(m, TILE); p.tiles_n = (int)sc_cdiv(n, TILE);
@@ -1263,7 +1264,25 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
         static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : (e && e[0] == '2') ? 2 : 0; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant, =2: 256x128 everywhere
         static const int big_min_n = [] { const char* e = getenv("SC_GEMM_NT_BIG_MINN"); return e ? atoi(e) : 512; }();   // A/B knob (1536: wide outputs only)
         if (variant == 0 && n >= big_min_n && m >= 4096) {
-            p.tiles_m = (int)sc_cdiv(m, B_M); p.tiles_n = (int)sc_cdiv(n, B_N);
+            // Tile-count quantisation: all tiles cost the same, so ceil(tiles / 256) rounds are paid even when the last one is
+            // nearly empty (600 tiles = 2.34 -> 3 rounds at N = 768).  When it pays, only the row tiles that fill WHOLE rounds go
+            // to the 256x256 kernel and the remaining rows are a second launch of the 256x128 kernel (half-size tiles: the
+            // leftover becomes one well-filled round that costs ~0.55 of a 256x256 round).  SC_GEMM_NT_SPLIT=0 disables.
+            static const bool split_on = [] { const char* e = getenv("SC_GEMM_NT_SPLIT"); return !(e && e[0] == '0'); }();
+            const int64_t tn_b = sc_cdiv(n, B_N), tm_b = sc_cdiv(m, B_M);
+            int64_t m_main = m;
+            {
+                const int64_t tiles = tm_b * tn_b, full = tiles / 256, rem = tiles - full * 256;
+                const bool cs_ok = !epi.colsum || epi.colsum_ws_bytes >= (size_t)1024 * n * sizeof(float);
+                if (split_on && cs_ok && full >= 1 && rem > 0) {
+                    const int64_t tm_main = (full * 256) / tn_b;
+                    const int64_t rows_rem = m - tm_main * B_M;
+                    const int64_t rounds_rem = sc_cdiv(sc_cdiv(rows_rem, T_M) * sc_cdiv(n, T_N), 256);
+                    if (tm_main > 0 && rows_rem > 0 && (double)full + 0.55 * (double)rounds_rem < (double)(full + 1) - 0.1) m_main = tm_main * B_M;
+                }
+            }
+            p.M = (int)m_main;
+            p.tiles_m = (int)sc_cdiv(m_main, B_M); p.tiles_n = (int)tn_b;
             const unsigned gridb = (unsigned)(p.tiles_m * p.tiles_n);
             if (epi.colsum && epi.colsum_ws_bytes >= (size_t)2 * p.tiles_m * n * sizeof(float) && sc_aligned(epi.colsum_ws, 16)) {
                 p.epi.cs_partial = (float*)epi.colsum_ws;   // [2 * tiles_m][N]; rows past M contribute nothing, every slot is written
@@ -1271,6 +1290,21 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
             }
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
+            cs_rows_done = m_main;
+            if (m_main < m) {   // the remaining rows: same operands and epilogue, pointers advanced by m_main rows
+                GemmBf16Params q = p;
+                q.epi.cs_partial = nullptr;
+                q.A = p.A + m_main * lda;
+                q.C = (char*)c + (size_t)m_main * ldc * (out_dtype == SC_F32 ? 4 : 2);
+                q.M = (int)(m - m_main);
+                if (q.epi.pre_out) q.epi.pre_out = (bf16_t*)q.epi.pre_out + m_main * epi.ld_aux;
+                if (q.epi.dgelu_pre) q.epi.dgelu_pre = (const bf16_t*)q.epi.dgelu_pre + m_main * epi.ld_aux;
+                if (q.epi.resid) q.epi.resid = (const char*)q.epi.resid + (size_t)m_main * epi.ld_aux * (epi.resid_dtype == SC_F32 ? 4 : 2);
+                q.tiles_m = (int)sc_cdiv(m - m_main, T_M); q.tiles_n = (int)sc_cdiv(n, T_N);
+                const unsigned grid2 = (unsigned)(q.tiles_m * q.tiles_n);
+                if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid2), dim3(512), 0, stream, q);
+                else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid2), dim3(512), 0, stream, q);
+            }
         } else if (variant == 3) {
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
@@ -1281,8 +1315,11 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     }
     SC_CHECK_LAUNCH();
     if (epi.colsum) {
-        if (cs_fused) return sc_colsum_reduce((const float*)epi.colsum_ws, 2 * p.tiles_m, n, epi.colsum, epi.colsum_accumulate, stream);
-        return sc_colsum(c, out_dtype, m, n, ldc, epi.colsum, epi.colsum_accumulate, epi.colsum_ws, epi.colsum_ws_bytes, (void*)stream);
+        if (!cs_fused) return sc_colsum(c, out_dtype, m, n, ldc, epi.colsum, epi.colsum_accumulate, epi.colsum_ws, epi.colsum_ws_bytes, (void*)stream);
+        SC_TRY(sc_colsum_reduce((const float*)epi.colsum_ws, 2 * p.tiles_m, n, epi.colsum, epi.colsum_accumulate, stream));
+        if (cs_rows_done < m)   // rows of the second launch: a pass over that part of C, added on top (stream-ordered, so ws is free again)
+            return sc_colsum((const char*)c + (size_t)cs_rows_done * ldc * (out_dtype == SC_F32 ? 4 : 2), out_dtype, m - cs_rows_done, n, ldc, epi.colsum, 1,
+                             epi.colsum_ws, epi.colsum_ws_bytes, (void*)stream);
     }
     return SC_OK;
 }

@@ -89,10 +89,10 @@ def test_gemm_bf16_nt(ops, m, n, k, out_dtype):
     assert_close(got, want, rt, 2e-3 * np.sqrt(k), f"gemm_bf16_nt {m}x{n}x{k}")
 
 
-@pytest.mark.parametrize("m,n,k", [(4096, 1536, 64), (4100, 1544, 192), (4352, 2304, 768), (5000, 1800, 128)])
+@pytest.mark.parametrize("m,n,k", [(4096, 1536, 64), (4100, 1544, 192), (4352, 2304, 768), (5000, 1800, 128), (10300, 2056, 128), (33000, 520, 64)])
 def test_gemm_bf16_nt_wide(ops, m, n, k):
-    """Shapes that dispatch to the 256x256 four-wave kernel (M >= 4096, N >= 1536): full and ragged tiles, odd / even K-tile
-    counts, every epilogue, checked element by element against fp64 on the same bf16 operands (computed on the device)."""
+    """Shapes that dispatch to the 256x256 AGPR kernel (M >= 4096, N >= 512): full and ragged tiles, odd / even K-tile counts, the
+    last two with more than 256 tiles so that the leftover rows go to a second launch of the 256x128 kernel; every epilogue, checked element by element against fp64 on the same bf16 operands (computed on the device)."""
     a, w = rnd(m, k, seed=21, dtype=torch.bfloat16).to(DEV), rnd(n, k, seed=22, scale=0.1, dtype=torch.bfloat16).to(DEV)
     bias, resid = rnd(n, seed=23).to(DEV), rnd(m, n, seed=24).to(DEV)
     acc = a.double() @ w.double().t()
@@ -128,7 +128,7 @@ def test_gemm_bf16_epilogue_gelu_series_accuracy(ops):
     assert_close(got, gelu_grad64(x.double()), 0, 3e-5, "GELU' series")
 
 
-@pytest.mark.parametrize("m,n,k", [(4100, 1544, 192), (8192, 768, 128), (300, 192, 128)])
+@pytest.mark.parametrize("m,n,k", [(4100, 1544, 192), (8192, 768, 128), (300, 192, 128), (10300, 2056, 64)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_nt_epilogue_colsum(ops, m, n, k, out_dtype):
     """Column sums of the stored output taken by the epilogue (256x256 kernel: fused; small problems: fallback pass): equal to
