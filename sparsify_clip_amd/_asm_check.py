@@ -12,7 +12,7 @@ from __future__ import annotations
 import re
 import subprocess
 
-KERNELS = ("gemm_bf16_nt_big_kernel", "gemm_bf16_tn_big_kernel")
+KERNELS = ("gemm_bf16_nt_big_kernel", "gemm_bf16_tn_big_kernel", "gemm_bf16_nt_pp_kernel")
 
 
 def _regs(tok: str):
@@ -73,8 +73,13 @@ def audit(asm_text: str):
         order = sorted(x for x in starts if x < len(ins))
         end_of = {b: (order[k + 1] if k + 1 < len(order) else len(ins)) for k, b in enumerate(order)}
 
+        # state = (ordered, loose): `ordered` = destination register sets of the in-flight inline-asm LDS reads in issue order (LDS
+        # operations return in order, so `s_waitcnt lgkmcnt(N)` retires all but the youngest N - provided no scalar load or
+        # compiler-issued LDS operation shares the counter at that moment); `loose` = reads whose order was lost at a merge of
+        # control flow, retired only by lgkmcnt(0)
         def run(b, state, report):
-            cur = set(state)
+            ordered, loose = list(state[0]), set(state[1])
+            foreign = state[2]          # a non-asm LGKM operation was issued while asm reads were in flight
             succ = []
             last_op = None
             for i in range(b, end_of[b]):
@@ -86,13 +91,23 @@ def audit(asm_text: str):
                     problems.append(f"{name}: scratch access `{text}`")
                 if not in_asm and op.startswith("v_accvgpr") and report:
                     problems.append(f"{name}: compiler-generated AGPR traffic `{text}`")
-                if op == "s_waitcnt" and "lgkmcnt(0)" in text:
-                    cur.clear()
+                m = re.search(r"lgkmcnt\((\d+)\)", text) if op == "s_waitcnt" else None
+                if m:
+                    n = int(m.group(1))
+                    if n == 0:
+                        ordered, loose, foreign = [], set(), False
+                    elif not foreign and not loose:
+                        ordered = ordered[-n:] if len(ordered) > n else ordered
                     continue
                 if in_asm:
                     if op.startswith("ds_read"):
-                        cur |= _regs(toks[0])
+                        ordered.append(frozenset(_regs(toks[0])))
                     continue
+                if (op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("ds_")) and (ordered or loose):
+                    foreign = True
+                cur = set(loose)
+                for r in ordered:
+                    cur |= r
                 used = set()
                 for x in toks:
                     used |= _regs(x)
@@ -104,23 +119,34 @@ def audit(asm_text: str):
                         succ.append(label_at[tgt])
             if last_op != "s_branch" and last_op != "s_endpgm" and end_of[b] < len(ins):
                 succ.append(end_of[b])
-            return cur, succ
+            return (tuple(ordered), frozenset(loose), foreign), succ
 
-        state_in = {b: set() for b in order}
+        def merge(a, b_):
+            if a is None:
+                return b_
+            if a[0] == b_[0]:
+                return (a[0], a[1] | b_[1], a[2] or b_[2])
+            loose = set(a[1]) | set(b_[1])
+            for r in list(a[0]) + list(b_[0]):
+                loose |= r
+            return ((), frozenset(loose), a[2] or b_[2])
+
+        state_in = {b: None for b in order}
+        state_in[order[0]] = ((), frozenset(), False)
         work = [order[0]]
-        seen = set()
         while work:
             b = work.pop()
             out, succ = run(b, state_in[b], False)
             for s_ in succ:
                 if s_ not in state_in:
                     continue
-                if not out <= state_in[s_] or s_ not in seen:
-                    state_in[s_] |= out
-                    seen.add(s_)
+                merged = merge(state_in[s_], out)
+                if merged != state_in[s_]:
+                    state_in[s_] = merged
                     work.append(s_)
         for b in order:
-            run(b, state_in[b], True)
+            if state_in[b] is not None:
+                run(b, state_in[b], True)
     return sorted(set(problems))
 
 

@@ -147,9 +147,18 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
             g = d->d_res_t;
         }
     }
+    // With a side stream the three weight-gradient GEMMs whose operands exist before the attention backward are held back until
+    // the main stream gets there (SC_BLOCK_DW_GATE=0: released as early as possible): GEMM kernels fill every CU and run one
+    // after the other whichever stream they come from, so issuing them early only makes them queue between the
+    // activation-gradient GEMMs, while the attention backward - latency bound, a few waves per CU - otherwise leaves the
+    // MFMA units idle for its whole duration.
+    static const bool gate_env = [] { const char* e = getenv("SC_BLOCK_DW_GATE"); return !(e && e[0] == '0'); }();
+    const bool gate = two && gate_env;
     // ---- MLP half: c_proj, GELU', c_fc
-    SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
+    if (!gate) {
+        SC_TRY(publish());
+        SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
+    }
     if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));   // reads the fp32 dx_out: main stream
     static const bool fuse_cs = [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum passes (A/B runs)
     const bool fcs = bf && fuse_cs;
@@ -159,9 +168,11 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
         e.colsum = d->g_b_fc1; e.colsum_ws = d->ws; e.colsum_ws_bytes = d->ws_bytes; e.colsum_accumulate = acc;
     }
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
-    SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
-    if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
+    if (!gate) {
+        SC_TRY(publish());
+        SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
+        if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
+    }
     SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
     // dx_mid = dx_out + LN2'(d_ln); the same kernel emits the operand copy and the out_proj bias gradient (column sums of dx_mid).
     // With a side stream the copy must not land in the buffer `g` that the side stream may still be reading (internal-cast case).
@@ -170,9 +181,18 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
                             d->g_ln2_g, d->g_ln2_b, d->g_b_o, acc, d->ws, d->ws_bytes, stream));
     const void* gm = bf ? (const void*)d->d_res_t : (const void*)d->dx_mid;
     // ---- attention half: out_proj, attention, in_proj
-    SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
+    if (!gate) {
+        SC_TRY(publish());
+        SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
+    }
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
+    if (gate) {   // everything the three GEMMs read (g, h_act, d_h, ln2_out, d_res_t, attn_out) is final here
+        SC_TRY(publish());
+        SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
+        SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
+        if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
+        SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
+    }
     // in_proj's bias gradient = column sums of d_qkv: taken by the attention backward while dq / dk / dv are in registers
     if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
     else SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));

@@ -393,15 +393,21 @@ __device__ __forceinline__ void ntb_read(bf16x8& dst, unsigned base) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(OFF) : "memory");
 }
 // one sub-step: 8 groups of 4 MFMAs; when LOAD, group I is followed by the read of next sub-step's a[I] (in place) and, for
-// I < 4, of its B fragment I into the other B set
-template <int I, bool LOAD>
+// I < 4, of its B fragment I into the other B set.  The 12 reads of a sub-step are therefore issued in the order
+// a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7.  LATE (measured, no gain, not used): enter the sub-step with a4..a7 still in flight
+// (s_waitcnt lgkmcnt(4)); LDS reads return in order, so before group I >= 4 "at most 11 outstanding" proves a[I] has landed.
+template <int I, bool LOAD, bool LATE = false>
 __device__ __forceinline__ void ntb_substep(bf16x8 (&a)[8], const bf16x8 (&b)[4], bf16x8 (&bn)[4], unsigned abase, unsigned bbase) {
+    if constexpr (LATE && I >= 4) {
+        if constexpr (LOAD) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(7 - I) : "memory");
+    }
     ntb_mfma<4 * I>(a, b); ntb_mfma<4 * I + 1>(a, b); ntb_mfma<4 * I + 2>(a, b); ntb_mfma<4 * I + 3>(a, b);
     if constexpr (LOAD) {
         ntb_read<I * 2048>(a[I], abase);
         if constexpr (I < 4) ntb_read<I * 2048>(bn[I], bbase);
     }
-    if constexpr (I + 1 < 8) ntb_substep<I + 1, LOAD>(a, b, bn, abase, bbase);
+    if constexpr (I + 1 < 8) ntb_substep<I + 1, LOAD, LATE>(a, b, bn, abase, bbase);
 }
 template <int N>
 __device__ __forceinline__ void ntb_zero() {
@@ -492,8 +498,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    ntb_read<0>(b0[0], fb00); ntb_read<2048>(b0[1], fb00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(b0[3], fb00);
-    ntb_read<0>(a[0], fa00); ntb_read<2048>(a[1], fa00); ntb_read<4096>(a[2], fa00); ntb_read<6144>(a[3], fa00);
+    // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7): the loop's counted waits rely on it
+    ntb_read<0>(a[0], fa00); ntb_read<0>(b0[0], fb00); ntb_read<2048>(a[1], fa00); ntb_read<2048>(b0[1], fb00);
+    ntb_read<4096>(a[2], fa00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(a[3], fa00); ntb_read<6144>(b0[3], fb00);
     ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
     // the loop only runs bodies that are followed by another tile, so every exit edge leads to code that starts with a wait:
     // no inline-asm LDS read is in flight when compiler-scheduled code (the epilogue) begins
@@ -602,6 +609,189 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
         }
         if (lane < 8 && ncol_ok) {
             float* dst = e.cs_partial + (int64_t)((m0 / B_M) * 2 + wm) * p.N + n;
+            *(f32x4*)dst = cs0;
+            *(f32x4*)(dst + 4) = cs1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NT, 256x128x32, two workgroups per CU on AGPRs
+// The 256x256 kernel above owns a whole CU, so its prologue (first LDS-DMA round trip) and its epilogue (accumulator read-back,
+// LDS slab, GELU / residual arithmetic, stores: ~12 us per tile against ~18 us of main loop at K = 768) run with the MFMA units
+// idle.  This kernel keeps the wave tile (128x64, accumulators in AGPRs a0..a127, same inline-assembly MFMA / LDS-read
+// statements) but a workgroup is 4 waves (2 x 2, one per SIMD) on a 256x128 tile with K-step 32: three 24-KiB stages = 72 KiB
+// of LDS and 256 registers per wave, so TWO workgroups share a CU and one's epilogue / prologue / LDS waits run under the
+// other's MFMAs - the overlap is the hardware's wave interleaving, no persistent scheduler needed.  64-byte LDS rows with the
+// slot swizzle of the 2-workgroup variant below (chunk c of row r at slot c ^ ((-(r >> 2)) & 3): conflict-free b128 reads).
+constexpr int PP_M = 256, PP_N = 128, PP_K = 32, PP_A = PP_M * 64, PP_STAGE = (PP_M + PP_N) * 64, PP_STAGES = 3;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_pp_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[PP_STAGES * PP_STAGE];   // 73728 B; the epilogue slabs (4 x 17408 B) reuse it
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int band = tile / (GROUP_M * p.tiles_n), r_band = tile - band * (GROUP_M * p.tiles_n);
+    const int rows = min(GROUP_M, p.tiles_m - band * GROUP_M);
+    const int cell = r_band / (rows * GROUP_N), r_cell = r_band - cell * (rows * GROUP_N);
+    const int gw = min(GROUP_N, p.tiles_n - cell * GROUP_N);
+    const int m0 = (band * GROUP_M + r_cell / gw) * PP_M, n0 = (cell * GROUP_N + r_cell % gw) * PP_N;
+
+    // staging: one wave instruction = 16 rows x 64 B; lane -> (row l >> 2, slot l & 3) holds chunk slot ^ f(row)
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
+    const bf16_t* ga[4];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ga[q] = p.A + (int64_t)min(m0 + wave * 64 + q * 16 + srow, p.M - 1) * p.lda + schunk * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) gb[q] = p.B + (int64_t)min(n0 + wave * 32 + q * 16 + srow, p.N - 1) * p.ldb + schunk * 8;
+
+    asm volatile("" ::: SC_ACC_AGPRS);   // reserve the accumulator AGPRs in the kernel descriptor
+
+    const int nk = p.K / PP_K;
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned fpos = (fq ^ ((-(frow >> 2)) & 3)) * 16;
+    const unsigned fa = lds0 + (wm * 128 + frow) * 64 + fpos, fb = lds0 + PP_A + (wn * 64 + frow) * 64 + fpos;
+
+#define PP_STAGE_LOAD(S, KT)                                                                          \
+    do {                                                                                              \
+        char* ab__ = smem + (S) * PP_STAGE + (wave * 64) * 64;                                        \
+        char* bb__ = smem + (S) * PP_STAGE + PP_A + (wave * 32) * 64;                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(ga[q] + (KT) * PP_K, ab__ + q * 16 * 64); \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) glds16(gb[q] + (KT) * PP_K, bb__ + q * 16 * 64); \
+    } while (0)
+    // One K-tile: tile KT has landed when at most the 6 LDS-DMA instructions of tile KT+1 are outstanding; the barrier also retires
+    // every read of tile KT-1, whose stage receives tile KT+2.  The 12 fragment reads are not software-pipelined: while this wave
+    // waits for them the other workgroup's wave on the same SIMD issues its MFMAs.
+#define PP_BODY(S, KT)                                                                                \
+    do {                                                                                              \
+        if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                           \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) PP_STAGE_LOAD(((S) + 2) % PP_STAGES, (KT) + 2);                            \
+        ntb_read<(S) * PP_STAGE + 0 * 1024>(b[0], fb); ntb_read<(S) * PP_STAGE + 1 * 1024>(b[1], fb); \
+        ntb_read<(S) * PP_STAGE + 2 * 1024>(b[2], fb); ntb_read<(S) * PP_STAGE + 3 * 1024>(b[3], fb); \
+        ntb_read<(S) * PP_STAGE + 0 * 1024>(a[0], fa); ntb_read<(S) * PP_STAGE + 1 * 1024>(a[1], fa); \
+        ntb_read<(S) * PP_STAGE + 2 * 1024>(a[2], fa); ntb_read<(S) * PP_STAGE + 3 * 1024>(a[3], fa); \
+        ntb_read<(S) * PP_STAGE + 4 * 1024>(a[4], fa); ntb_read<(S) * PP_STAGE + 5 * 1024>(a[5], fa); \
+        ntb_read<(S) * PP_STAGE + 6 * 1024>(a[6], fa); ntb_read<(S) * PP_STAGE + 7 * 1024>(a[7], fa); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        ntb_substep<0, false>(a, b, b, 0u, 0u);                                                       \
+    } while (0)
+
+    bf16x8 a[8], b[4];
+    PP_STAGE_LOAD(0, 0);
+    if (nk > 1) PP_STAGE_LOAD(1, 1);
+    ntb_zero<0>();
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+        PP_BODY(0, kt);
+        PP_BODY(1, kt + 1);
+        PP_BODY(2, kt + 2);
+    }
+    if (kt < nk) {
+        PP_BODY(0, kt);
+        if (kt + 1 < nk) PP_BODY(1, kt + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
+#undef PP_BODY
+#undef PP_STAGE_LOAD
+
+    // Epilogue: as in the 256x128 kernel (per-wave 64x64 LDS slab, row-major 16-byte pieces), two passes of 64 rows per wave.
+    const EpiParams& e = p.epi;
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + ecol;
+    const bool ncol_ok = n < p.N;
+    const int nn = ncol_ok ? n : 0;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    const bool has_pre = e.dgelu_pre != nullptr, has_res = e.resid != nullptr, res_f32 = e.resid_dtype == SC_F32;
+    if (e.bias) { bias0 = *(const f32x4*)(e.bias + nn); bias1 = *(const f32x4*)(e.bias + nn + 4); }
+    __syncthreads();   // every wave is done reading the last K-tile
+    float* slab = (float*)smem + wave * (64 * 68);   // 4 x 17408 B <= 3 stages
+    // fused column sums of the stored output (bias gradient of the producing layer): per lane 8 columns over all of its rows
+    const bool do_cs = e.cs_partial != nullptr;
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int mw = m0 + wm * 128 + h * 64;
+        if (h == 0) ntb_to_slab<0, 0>(slab + frow * 68 + 4 * fq);
+        else ntb_to_slab<0, 1>(slab + frow * 68 + 4 * fq);
+        if (ncol_ok) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {   // 4 rows per lane at a time: their GELU' / residual operands are requested together
+            uint4 hpre[4];
+            f32x4 res0[4], res1[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = min(mw + (4 * g + it) * 8 + erow, p.M - 1);
+                const int64_t off = (int64_t)m * e.ld_aux + nn;
+                if (has_pre) hpre[it] = *(const uint4*)((const bf16_t*)e.dgelu_pre + off);
+                if (has_res) {
+                    if (res_f32) {
+                        res0[it] = *(const f32x4*)((const float*)e.resid + off);
+                        res1[it] = *(const f32x4*)((const float*)e.resid + off + 4);
+                    } else {
+                        res0[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off);
+                        res1[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = (4 * g + it) * 8 + erow;
+                const int m = mw + row;
+                if (m >= p.M) continue;
+                f32x4 v0 = *(const f32x4*)(slab + row * 68 + ecol) * e.alpha + bias0;
+                f32x4 v1 = *(const f32x4*)(slab + row * 68 + ecol + 4) * e.alpha + bias1;
+                const int64_t off = (int64_t)m * e.ld_aux + n;
+                if (e.pre_out) {
+                    io<bf16_t>::st4((bf16_t*)e.pre_out + off, v0);
+                    io<bf16_t>::st4((bf16_t*)e.pre_out + off + 4, v1);
+                }
+                if (e.act == 1) {
+                    v0 = gelu_fast4(v0); v1 = gelu_fast4(v1);
+                }
+                if (has_pre) {
+                    const uint4 hh = hpre[it];
+                    v0 = gelu_grad_mul4(v0, hh.x, hh.y); v1 = gelu_grad_mul4(v1, hh.z, hh.w);
+                }
+                if (has_res) { v0 += res0[it]; v1 += res1[it]; }
+                if (OUT_F32) {
+                    float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                    if (e.beta != 0.f) { v0 += *(const f32x4*)cp * e.beta; v1 += *(const f32x4*)(cp + 4) * e.beta; }
+                    *(f32x4*)cp = v0;
+                    *(f32x4*)(cp + 4) = v1;
+                    if (do_cs) { cs0 += v0; cs1 += v1; }
+                } else {
+                    uint4 u;
+                    u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
+                    u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
+                    u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
+                    u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+                    *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
+                    if (do_cs) {   // the values as stored (bf16-rounded): identical to a pass over C
+                        cs0[0] += __uint_as_float(u.x << 16); cs0[1] += __uint_as_float(u.x & 0xffff0000u);
+                        cs0[2] += __uint_as_float(u.y << 16); cs0[3] += __uint_as_float(u.y & 0xffff0000u);
+                        cs1[0] += __uint_as_float(u.z << 16); cs1[1] += __uint_as_float(u.z & 0xffff0000u);
+                        cs1[2] += __uint_as_float(u.w << 16); cs1[3] += __uint_as_float(u.w & 0xffff0000u);
+                    }
+                }
+            }
+          }
+        }
+    }
+    if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per (row tile, wave row)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cs0[j] += __shfl_xor(cs0[j], 8, 64);  cs1[j] += __shfl_xor(cs1[j], 8, 64);
+            cs0[j] += __shfl_xor(cs0[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64);
+            cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
+        }
+        if (lane < 8 && ncol_ok) {
+            float* dst = e.cs_partial + (int64_t)((m0 / PP_M) * 2 + wm) * p.N + n;
             *(f32x4*)dst = cs0;
             *(f32x4*)(dst + 4) = cs1;
         }
@@ -1261,7 +1451,7 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     } else {
         p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
         const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
-        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : (e && e[0] == '2') ? 2 : 0; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant, =2: 256x128 everywhere
+        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : (e && e[0] == '2') ? 2 : (e && e[0] == 'p') ? 4 : 0; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant, =2: 256x128 everywhere
         static const int big_min_n = [] { const char* e = getenv("SC_GEMM_NT_BIG_MINN"); return e ? atoi(e) : 512; }();   // A/B knob (1536: wide outputs only)
         if (variant == 0 && n >= big_min_n && m >= 4096) {
             // Tile-count quantisation: all tiles cost the same, so ceil(tiles / 256) rounds are paid even when the last one is
@@ -1305,6 +1495,16 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                 if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid2), dim3(512), 0, stream, q);
                 else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid2), dim3(512), 0, stream, q);
             }
+        } else if (variant == 4 && k % PP_K == 0) {
+            p.tiles_m = (int)sc_cdiv(m, PP_M); p.tiles_n = (int)sc_cdiv(n, PP_N);
+            const unsigned gridp = (unsigned)(p.tiles_m * p.tiles_n);
+            if (epi.colsum && epi.colsum_ws_bytes >= (size_t)2 * p.tiles_m * n * sizeof(float) && sc_aligned(epi.colsum_ws, 16)) {
+                p.epi.cs_partial = (float*)epi.colsum_ws;
+                cs_fused = true;
+                cs_rows_done = m;
+            }
+            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3(gridp), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3(gridp), dim3(256), 0, stream, p);
         } else if (variant == 3) {
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
