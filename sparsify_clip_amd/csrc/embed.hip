@@ -42,12 +42,32 @@ __global__ __launch_bounds__(256) void vit_tokens_bwd_copy_kernel(const float* d
 }
 
 // out[s][c] (+)= sum_b dx[b][s][c];  optionally extra[c] (+)= the s == 0 row (class-embedding gradient)
+// A workgroup owns 64 columns of one position s: 16 threads x 16 bytes across, 16 batch groups down (b = ty, ty + 16, ...), four
+// loads in flight per thread; the 16 group sums are combined through LDS in a fixed order.  grid = (ceil(width / 64), seq).
 __global__ __launch_bounds__(256) void batch_sum_kernel(const float* dx, int batch, int seq, int width, float* out, float* extra, int accumulate) {
+    __shared__ f32x4 sm[16][17];
     const int s = blockIdx.y;
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= width) return;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = (blockIdx.x * 16 + tx) * 4;
+    const bool live = c < width;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < batch; ++b) acc += *(const f32x4*)(dx + ((int64_t)b * seq + s) * width + c);
+    if (live) {
+        const float* p = dx + (int64_t)s * width + c;
+        const int64_t stride = (int64_t)seq * width;
+        int b = ty;
+        for (; b + 48 < batch; b += 64) {
+            const f32x4 v0 = *(const f32x4*)(p + b * stride), v1 = *(const f32x4*)(p + (b + 16) * stride);
+            const f32x4 v2 = *(const f32x4*)(p + (b + 32) * stride), v3 = *(const f32x4*)(p + (b + 48) * stride);
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; b < batch; b += 16) acc += *(const f32x4*)(p + b * stride);
+    }
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty != 0 || !live) return;
+    acc = sm[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) acc += sm[k][tx];
     if (out) {
         f32x4* o = (f32x4*)(out + (int64_t)s * width + c);
         *o = accumulate ? *o + acc : acc;
@@ -68,7 +88,10 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* toke
         *(f32x4*)(x + row * width + c) = *(const f32x4*)(tok_emb + tok * width + c) + *(const f32x4*)(pos + (int64_t)s * width + c);
 }
 
-// one wave per sorted position; only the head of a run of equal tokens works: it adds the run's rows in sorted order
+// one wave per sorted position; only the head of a run of equal tokens works: it adds the run's rows in sorted order.
+// Frequent tokens (start / end of text: one occurrence per caption) make runs of `batch` rows: the run length is found 64
+// positions at a time with a ballot and the rows are fetched 16 at a time (independent loads in flight), added in run order -
+// the same sum, bit for bit, as the one-row-at-a-time loop, without its chain of dependent memory latencies.
 __global__ __launch_bounds__(256) void token_scatter_kernel(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted,
                                                             int width, int64_t vocab, float* d_tok_emb) {
     const int lane = threadIdx.x & 63;
@@ -77,11 +100,28 @@ __global__ __launch_bounds__(256) void token_scatter_kernel(const float* dx, con
     const int64_t tok = sorted_tokens[i];
     if (i > 0 && sorted_tokens[i - 1] == tok) return;
     if (tok < 0 || tok >= vocab) return;
+    int64_t len = 0;
+    for (int64_t base = i;; base += 64) {
+        const int64_t k = base + lane;
+        const bool same = k < n_sorted && sorted_tokens[k] == tok;
+        const unsigned long long m = __ballot(same);
+        if (m == ~0ull) { len += 64; continue; }
+        len += __builtin_ctzll(~m);
+        break;
+    }
     for (int c0 = 0; c0 < width; c0 += 256) {
         const int c = c0 + lane * 4;
         if (c >= width) continue;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int64_t k = i; k < n_sorted && sorted_tokens[k] == tok; ++k) acc += *(const f32x4*)(dx + order[k] * width + c);
+        int64_t k = 0;
+        for (; k + 16 <= len; k += 16) {
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = *(const f32x4*)(dx + order[i + k + j] * width + c);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += v[j];
+        }
+        for (; k < len; ++k) acc += *(const f32x4*)(dx + order[i + k] * width + c);
         f32x4* o = (f32x4*)(d_tok_emb + tok * width + c);
         *o += acc;
     }
@@ -197,7 +237,7 @@ extern "C" int sc_vit_tokens_bwd(const float* dx, int64_t batch, int64_t seq, in
     if (dtype == SC_BF16) hipLaunchKernelGGL(vit_tokens_bwd_copy_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), dx, (int)seq, (int)width, (bf16_t*)d_patch_out);
     else if (dtype == SC_F32) hipLaunchKernelGGL(vit_tokens_bwd_copy_kernel<float>, grid, dim3(256), 0, ST(stream), dx, (int)seq, (int)width, (float*)d_patch_out);
     else return sc_set_error(SC_ERR_DTYPE, "sc_vit_tokens_bwd: bad dtype");
-    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 1024), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 64), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
                        d_pos, d_cls, accumulate);
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -219,7 +259,7 @@ extern "C" int sc_text_embed_bwd(const float* dx, const int64_t* sorted_tokens, 
         hipError_t e = hipMemsetAsync(d_tok_emb, 0, (size_t)vocab * width * sizeof(float), ST(stream));
         if (e != hipSuccess) return sc_set_error((int)e, "sc_text_embed_bwd: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 1024), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 64), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
                        d_pos, (float*)nullptr, accumulate);
     if (n_sorted > 0)
         hipLaunchKernelGGL(token_scatter_kernel, dim3((unsigned)sc_cdiv(n_sorted, 4)), dim3(256), 0, ST(stream), dx, sorted_tokens, order, n_sorted, (int)width,
