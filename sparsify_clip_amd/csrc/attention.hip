@@ -5,6 +5,7 @@
 // storage dtypes, so the same kernel serves the fp32 parity path and the bf16 path.
 // The text tower uses the additive causal mask of open_clip (-inf above the diagonal).
 #include "common.h"
+#include "gemm_epilogue.h"
 #include <stdlib.h>
 
 int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
@@ -176,12 +177,102 @@ int set_lds(K kernel, size_t bytes) {
 int check(const char* who, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads) {
     SC_REQUIRE(dtype == SC_BF16 || dtype == SC_F32, SC_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
     SC_REQUIRE(batch > 0 && seq > 0 && heads > 0 && width == heads * HD, SC_ERR_SHAPE, "%s: width %lld must be heads*64", who, (long long)width);
-    SC_REQUIRE(seq <= (dtype == SC_BF16 ? 272 : 128), SC_ERR_SHAPE, "%s: sequence length %lld is not supported (bf16: <= 272, fp32: <= 128)", who, (long long)seq);
+    SC_REQUIRE(seq <= (dtype == SC_BF16 ? 272 : 128), SC_ERR_SHAPE,
+               "%s: sequence length %lld is not supported (bf16: <= 272, fp32: <= 128; longer fp32 sequences need a workspace and go through sc_block_fwd/bwd)",
+               who, (long long)seq);
     SC_REQUIRE(batch * heads < (1ll << 31), SC_ERR_SHAPE, "%s: grid too large", who);
     return SC_OK;
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------ fp32, 128 < seq <= 1024
+// Parity path for long sequences (ViT-L/14: 257 tokens), one head at a time out of three pieces that exist already: the fp32
+// MFMA GEMM on strided views of qkv (scores = Q K^T, O = P V, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q), a row softmax
+// and the dS row kernel below.  Needs 2 * seq^2 floats of workspace, which the public sc_attention_* entry points do not
+// have: this path is reached through sc_block_fwd / sc_block_bwd (block.hip).  Launch bound by design: 3 launches per head
+// forward, 8 backward.
+int sc_gemm_f32_launch(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       float* c, int64_t ldc, const EpiParams& epi, hipStream_t stream);
+
+namespace {
+// one wave per row: p[i][j] = softmax_j(scale * s[i][j]) over j < S (causal: j <= i), in place
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* p, int S, int64_t ld, float scale, int causal) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= S) return;
+    float* row = p + (int64_t)i * ld;
+    const int n = causal ? i + 1 : S;
+    float m = -INFINITY;
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, row[j] * scale);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < n; j += 64) l += expf(row[j] * scale - m);
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+    for (int j = lane; j < S; j += 64) row[j] = j < n ? expf(row[j] * scale - m) * inv : 0.f;
+}
+// dS[i][j] = P[i][j] * (dP[i][j] - sum_j P[i][j] dP[i][j]) * scale, written over dP
+__global__ __launch_bounds__(256) void attn_ds_rows_f32_kernel(const float* p, float* dp, int S, int64_t ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= S) return;
+    const float* pr = p + (int64_t)i * ld;
+    float* dr = dp + (int64_t)i * ld;
+    float delta = 0.f;
+    for (int j = lane; j < S; j += 64) delta += pr[j] * dr[j];
+    delta = wave_sum(delta);
+    for (int j = lane; j < S; j += 64) dr[j] = pr[j] * (dr[j] - delta) * scale;
+}
+}  // namespace
+
+int sc_attention_f32_composed_fwd(const float* qkv, float* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, void* ws,
+                                  size_t ws_bytes, hipStream_t st) {
+    SC_REQUIRE(qkv && out && ws, SC_ERR_ARG, "attention (fp32, long): null argument");
+    SC_REQUIRE(seq <= 1024 && width == heads * 64, SC_ERR_SHAPE, "attention (fp32, long): seq %lld > 1024 or width != heads*64", (long long)seq);
+    const int64_t sp = (seq + 3) / 4 * 4;
+    SC_REQUIRE(ws_bytes >= (size_t)seq * sp * sizeof(float) && sc_aligned(ws, 16), SC_ERR_WORKSPACE, "attention (fp32, long): workspace too small");
+    float* P = (float*)ws;
+    const int64_t ld = 3 * width;
+    const EpiParams plain = epi_plain();
+    for (int64_t b = 0; b < batch; ++b)
+        for (int64_t h = 0; h < heads; ++h) {
+            const float* q = qkv + b * seq * ld + h * 64;
+            SC_TRY(sc_gemm_f32_launch(0, 1, seq, seq, 64, q, ld, q + width, ld, P, sp, plain, st));
+            hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)sc_cdiv(seq, 4)), dim3(256), 0, st, P, (int)seq, sp, 0.125f, causal);
+            SC_TRY(sc_gemm_f32_launch(0, 0, seq, 64, seq, P, sp, q + 2 * width, ld, out + b * seq * width + h * 64, width, plain, st));
+        }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+int sc_attention_f32_composed_bwd(const float* qkv, const float* d_out, float* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                                  void* ws, size_t ws_bytes, hipStream_t st) {
+    SC_REQUIRE(qkv && d_out && d_qkv && ws, SC_ERR_ARG, "attention (fp32, long): null argument");
+    SC_REQUIRE(seq <= 1024 && width == heads * 64, SC_ERR_SHAPE, "attention (fp32, long): seq %lld > 1024 or width != heads*64", (long long)seq);
+    const int64_t sp = (seq + 3) / 4 * 4;
+    SC_REQUIRE(ws_bytes >= (size_t)2 * seq * sp * sizeof(float) && sc_aligned(ws, 16), SC_ERR_WORKSPACE, "attention (fp32, long): workspace too small");
+    float* P = (float*)ws;
+    float* D = P + seq * sp;
+    const int64_t ld = 3 * width;
+    const EpiParams plain = epi_plain();
+    for (int64_t b = 0; b < batch; ++b)
+        for (int64_t h = 0; h < heads; ++h) {
+            const float* q = qkv + b * seq * ld + h * 64;
+            const float *k = q + width, *v = q + 2 * width;
+            const float* go = d_out + b * seq * width + h * 64;
+            float* dq = d_qkv + b * seq * ld + h * 64;
+            SC_TRY(sc_gemm_f32_launch(0, 1, seq, seq, 64, q, ld, k, ld, P, sp, plain, st));                     // scores
+            hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)sc_cdiv(seq, 4)), dim3(256), 0, st, P, (int)seq, sp, 0.125f, causal);
+            SC_TRY(sc_gemm_f32_launch(1, 0, seq, 64, seq, P, sp, go, width, dq + 2 * width, ld, plain, st));    // dV = P^T dO
+            SC_TRY(sc_gemm_f32_launch(0, 1, seq, seq, 64, go, width, v, ld, D, sp, plain, st));                  // dP = dO V^T
+            hipLaunchKernelGGL(attn_ds_rows_f32_kernel, dim3((unsigned)sc_cdiv(seq, 4)), dim3(256), 0, st, P, D, (int)seq, sp, 0.125f);
+            SC_TRY(sc_gemm_f32_launch(0, 0, seq, 64, seq, D, sp, k, ld, dq, ld, plain, st));                     // dQ = dS K
+            SC_TRY(sc_gemm_f32_launch(1, 0, seq, 64, seq, D, sp, q, ld, dq + width, ld, plain, st));            // dK = dS^T Q
+        }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
 
 extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                                 void* stream) {

@@ -17,6 +17,11 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
                            float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta);
 size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r);
 
+int sc_attention_f32_composed_fwd(const float* qkv, float* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, void* ws,
+                                  size_t ws_bytes, hipStream_t st);
+int sc_attention_f32_composed_bwd(const float* qkv, const float* d_out, float* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
+                                  void* ws, size_t ws_bytes, hipStream_t st);
+
 namespace {
 
 // y[rows,n] = x[rows,k] W[n,k]^T (+ epilogue); W in torch [out,in] layout
@@ -81,7 +86,10 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
     EpiParams e = epi_plain();
     e.bias = d->b_qkv;
     SC_TRY(linear_fwd(dt, rows, 3 * W, W, d->ln1_out, d->w_qkv, d->qkv, dt, e, st));
-    SC_TRY(sc_attention_fwd(d->qkv, d->attn_out, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
+    if (dt == SC_F32 && d->seq > 128)   // fp32 parity path of long sequences: composed from the fp32 GEMM, needs a workspace
+        SC_TRY(sc_attention_f32_composed_fwd((const float*)d->qkv, (float*)d->attn_out, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, (hipStream_t)stream));
+    else
+        SC_TRY(sc_attention_fwd(d->qkv, d->attn_out, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     // out_proj (+bias) + residual -> fp32 x_mid
     e = epi_plain();
     e.bias = d->b_o; e.resid = d->x_in; e.resid_dtype = SC_F32; e.ld_aux = W;
@@ -194,7 +202,9 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
         SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
     }
     // in_proj's bias gradient = column sums of d_qkv: taken by the attention backward while dq / dk / dv are in registers
-    if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
+    if (dt == SC_F32 && d->seq > 128)
+        SC_TRY(sc_attention_f32_composed_bwd((const float*)d->qkv, (const float*)d->d_attn, (float*)d->d_qkv, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, st));
+    else if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
     else SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     SC_TRY(publish());
     SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));

@@ -30,8 +30,7 @@ def _pair(pkg, name, precision, seed=3):
     return ref, model
 
 
-@pytest.mark.parametrize("name", ["tiny", "test-small"])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name,precision", [("tiny", "fp32"), ("tiny", "bf16"), ("test-small", "fp32"), ("test-small", "bf16"), ("test-l14", "fp32")])
 def test_towers_forward_backward(pkg, name, precision):
     from oracle.clip_model import synthetic_batch
     ref, model = _pair(pkg, name, precision)
@@ -156,6 +155,34 @@ def test_training_trajectory_fp32(pkg, loss_type, kw):
         assert rel_err(model.param(pname), dict(ref_model.named_parameters())[pname]) < 1e-4, pname
     if cfg["anchor_temperature_learnable"]:
         assert abs(float(gpu.temperature.detach()) - float(cpu.temperature.detach())) < 1e-6
+
+
+def test_training_trajectory_fp32_vit_l14_geometry(pkg):
+    """The same 1e-4 per-step bar on ViT-L/14's geometry (BASELINE config 5's model family at a small width): patch 14 -> K = 588
+    patch GEMM, 257 image tokens -> the long-sequence fp32 attention (fp32 GEMMs + row softmax per head), experiment-10 loss stack."""
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    from sparsify_clip_amd.train import Trainer
+    cfg = _config("only_lunif_n_then_anchor+ALPHA*lalign+BETA*lunif(centroids)", batch_size=6, model="test-l14")
+    steps_per_epoch = 2
+    ref_model = create_model("test-l14", seed=9)
+    cpu = CpuTrainer(cfg, steps_per_epoch, model=ref_model)
+    model = pkg.ClipModel("test-l14", device=DEV, precision="fp32")
+    model.load_state_dict(ref_model.state_dict())
+    gpu = Trainer(cfg, DEV, steps_per_epoch, model=model)
+    k = 0
+    for epoch in range(2):
+        cpu.epoch = gpu.epoch = epoch
+        for _ in range(steps_per_epoch):
+            images_np, tokens_np = synthetic_batch(300 + k, cfg["batch_size"], ref_model.cfg)
+            images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+            want = cpu.step(images, tokens).item()
+            got = gpu.step(images.to(DEV), tokens.to(DEV)).item()
+            assert abs(got - want) <= 1e-4 * abs(want), (k, got, want)
+            k += 1
+    # (not in_proj_bias: its key part has an exactly-zero gradient - softmax is shift invariant - so Adam amplifies rounding noise there)
+    for pname in ["visual.proj", "visual.conv1.weight", "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.0.mlp.c_fc.bias"]:
+        assert rel_err(model.param(pname), dict(ref_model.named_parameters())[pname]) < 1e-4, pname
 
 
 def test_bf16_step_close_to_fp32(pkg):
