@@ -16,6 +16,8 @@ Parameter order = reverse of the order gradients become final in the backward, p
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 
@@ -389,7 +391,8 @@ class ClipModel:
         if self._side is None:
             self._side = {}
         if tower.kind not in self._side:
-            self._side[tower.kind] = (torch.cuda.Stream(device=self.device), [torch.cuda.Event(), torch.cuda.Event()])
+            prio = -1 if os.environ.get("SC_STREAM_PRIO", "") == "s" else 0
+            self._side[tower.kind] = (torch.cuda.Stream(device=self.device, priority=prio), [torch.cuda.Event(), torch.cuda.Event()])
         side, side_done = self._side[tower.kind]
         n = dx.numel()
         dx_t = [self._scratch[f"bwd.{tower.kind}.dx_t.{k}"][:n] for k in range(3)]

@@ -88,7 +88,8 @@ class Trainer:
         # kernels (LayerNorm, attention, embedding) overlap the image tower's GEMMs and vice versa
         main = torch.cuda.current_stream()
         if self.text_stream is None:
-            self.text_stream = torch.cuda.Stream(device=self.device)
+            # SC_STREAM_PRIO=t/s: high priority for the text tower's stream / for the weight-gradient side streams (A/B knob; default: equal)
+            self.text_stream = torch.cuda.Stream(device=self.device, priority=-1 if os.environ.get("SC_STREAM_PRIO", "") == "t" else 0)
         self.text_stream.wait_stream(main)
         with torch.cuda.stream(self.text_stream):
             txt_e = m.text_forward(tokens)                                         # :769
