@@ -177,3 +177,32 @@ def test_model_layout_without_gpu():
         assert spans[0][0] == 0 and spans[-1][1] == stub.n_trainable
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert all(off % 64 == 0 for off, _ in stub.slots.values())
+
+
+def test_asm_audit_flags_the_three_hazards():
+    """The build-time audit of the inline-assembly GEMM kernels (_asm_check.py) on hand-written snippets: a clean loop passes;
+    compiler AGPR traffic, scratch, and a VALU instruction on a register whose inline-asm LDS read is still in flight are flagged;
+    a counted lgkmcnt wait retires the older reads only."""
+    from sparsify_clip_amd._asm_check import audit
+
+    def kernel(body):
+        return ".globl _Z23gemm_bf16_nt_big_kernelv\n_Z23gemm_bf16_nt_big_kernelv:\n" + body + "\n\ts_endpgm\n.Lfunc_end0:\n"
+
+    asm_read = lambda dst, addr="v9": f"\t;;#ASMSTART\n\tds_read_b128 {dst}, {addr} offset:0\n\t;;#ASMEND\n"
+    mfma = "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[20:23], a[0:3]\n\t;;#ASMEND\n"
+    clean = asm_read("v[10:13]") + asm_read("v[20:23]") + "\ts_waitcnt lgkmcnt(0)\n" + mfma + "\tv_add_u32_e32 v10, 1, v10\n"
+    assert audit(kernel(clean)) == []
+    early_use = asm_read("v[10:13]") + "\tv_add_u32_e32 v11, 1, v11\n\ts_waitcnt lgkmcnt(0)\n" + mfma
+    assert any("still in flight" in p for p in audit(kernel(early_use)))
+    assert any("AGPR traffic" in p for p in audit(kernel(clean + "\tv_accvgpr_write_b32 a5, v3\n")))
+    assert any("scratch" in p for p in audit(kernel(clean + "\tscratch_store_dword off, v3, off\n")))
+    # two reads, lgkmcnt(1): the older one (v[10:13]) has landed, the younger (v[20:23]) has not
+    counted = asm_read("v[10:13]") + asm_read("v[20:23]") + "\ts_waitcnt lgkmcnt(1)\n"
+    assert audit(kernel(counted + "\tv_add_u32_e32 v10, 1, v10\n\ts_waitcnt lgkmcnt(0)\n")) == []
+    assert any("still in flight" in p for p in audit(kernel(counted + "\tv_add_u32_e32 v20, 1, v20\n\ts_waitcnt lgkmcnt(0)\n")))
+    # a read in flight across a loop back-edge reaches code after the loop unless that code starts with a wait
+    loop = ".LBB0_1:\n" + "\ts_waitcnt lgkmcnt(0)\n" + mfma + asm_read("v[10:13]") + "\ts_cbranch_scc1 .LBB0_1\n"
+    assert any("still in flight" in p for p in audit(kernel(loop + "\tv_mov_b32_e32 v10, 0\n")))
+    assert audit(kernel(loop + "\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v10, 0\n")) == []
+    # other kernels in the same file are not audited
+    assert audit(".globl _Z5otherv\n_Z5otherv:\n\tscratch_store_dword off, v3, off\n\ts_endpgm\n.Lfunc_end1:\n") == []
