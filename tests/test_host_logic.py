@@ -111,9 +111,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"sc_gemm_epilogue", "sc_block_desc"}
     assert declared == set(_lib.LIB.protos), declared ^ set(_lib.LIB.protos)
     dll = _lib.LIB.load()                      # raises if a declared symbol is not exported
-    import re
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sparsify_hip.h")) as f:
-        assert dll.sc_abi_version() == int(re.search(r"#define\s+SC_ABI_VERSION\s+(\d+)", f.read()).group(1))
+    assert dll.sc_abi_version() == int(re.search(r"#define\s+SC_ABI_VERSION\s+(\d+)", header).group(1))
     assert dll.sc_abi_sizeof(0) == ctypes.sizeof(_lib.BlockDesc)
     assert dll.sc_abi_sizeof(1) == ctypes.sizeof(_lib.GemmEpilogue)
     assert dll.sc_loss_workspace_bytes(8192, 512) > 8192 * 8192 * 4
