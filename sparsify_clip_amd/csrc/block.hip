@@ -22,7 +22,16 @@ int sc_attention_f32_composed_fwd(const float* qkv, float* out, int64_t batch, i
 int sc_attention_f32_composed_bwd(const float* qkv, const float* d_out, float* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                                   void* ws, size_t ws_bytes, hipStream_t st);
 
+int sc_gelu_fwd_bf16(const void* pre, void* act, int64_t n_elems, hipStream_t st);
+int sc_dgelu_mul_colsum_bf16(void* dh, const void* pre, int64_t rows, int64_t n, float* colsum, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
 namespace {
+// SC_BLOCK_UNFUSE_GELU=1: GELU / GELU' as separate HBM-bound kernels instead of GEMM epilogues (A/B: the step is GEMM-bound and other
+// kernels run in the GEMMs' shadow, so moving epilogue work out of the GEMMs might pay; bf16 path only)
+bool unfuse_gelu() {
+    static const bool on = [] { const char* e = getenv("SC_BLOCK_UNFUSE_GELU"); return e && e[0] == '1'; }();
+    return on;
+}
 
 // y[rows,n] = x[rows,k] W[n,k]^T (+ epilogue); W in torch [out,in] layout
 int linear_fwd(int dtype, int64_t rows, int64_t n, int64_t k, const void* x, const void* w, void* y, int out_dtype, const EpiParams& epi,
@@ -97,8 +106,14 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
     // ln_2 -> c_fc (+bias, keep pre-activation) -> GELU
     SC_TRY(sc_layernorm_fwd(d->x_mid, rows, W, d->ln2_g, d->ln2_b, d->ln2_out, dt, d->ln2_mean, d->ln2_rstd, stream));
     e = epi_plain();
-    e.bias = d->b_fc1; e.pre_out = d->h_pre; e.act = 1; e.ld_aux = MLP;
-    SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_act, dt, e, st));
+    if (dt == SC_BF16 && unfuse_gelu()) {
+        e.bias = d->b_fc1;
+        SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_pre, dt, e, st));
+        SC_TRY(sc_gelu_fwd_bf16(d->h_pre, d->h_act, rows * MLP, st));
+    } else {
+        e.bias = d->b_fc1; e.pre_out = d->h_pre; e.act = 1; e.ld_aux = MLP;
+        SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_act, dt, e, st));
+    }
     // c_proj (+bias) + residual -> fp32 x_out
     e = epi_plain();
     e.bias = d->b_fc2; e.resid = d->x_mid; e.resid_dtype = SC_F32; e.ld_aux = W;
@@ -171,11 +186,15 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     static const bool fuse_cs = [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum passes (A/B runs)
     const bool fcs = bf && fuse_cs;
     EpiParams e = epi_plain();
-    e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
-    if (fcs) {   // c_fc's bias gradient = column sums of d_h: taken in the epilogue that produces d_h (main stream, main workspace)
-        e.colsum = d->g_b_fc1; e.colsum_ws = d->ws; e.colsum_ws_bytes = d->ws_bytes; e.colsum_accumulate = acc;
+    const bool ug = bf && fcs && unfuse_gelu();
+    if (!ug) {
+        e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
+        if (fcs) {   // c_fc's bias gradient = column sums of d_h: taken in the epilogue that produces d_h (main stream, main workspace)
+            e.colsum = d->g_b_fc1; e.colsum_ws = d->ws; e.colsum_ws_bytes = d->ws_bytes; e.colsum_accumulate = acc;
+        }
     }
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
+    if (ug) SC_TRY(sc_dgelu_mul_colsum_bf16(d->d_h, d->h_pre, rows, MLP, d->g_b_fc1, acc, d->ws, d->ws_bytes, st));
     if (!gate) {
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));

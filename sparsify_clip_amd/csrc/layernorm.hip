@@ -186,6 +186,66 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t rows, i
     *(f32x4*)(partial + (int64_t)blockIdx.y * n + col) = s;
 }
 
+// act = GELU(pre), bf16 -> bf16, 8 elements (16 bytes) per thread (un-fused form of the c_fc epilogue, SC_BLOCK_UNFUSE_GELU=1)
+__global__ __launch_bounds__(256) void gelu_fwd_bf16_kernel(const bf16_t* pre, bf16_t* act, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 u = *(const uint4*)(pre + i * 8);
+    const f32x2 a = gelu_fast2(f32x2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)});
+    const f32x2 b = gelu_fast2(f32x2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)});
+    const f32x2 c = gelu_fast2(f32x2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)});
+    const f32x2 d = gelu_fast2(f32x2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)});
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(a[0]) | ((unsigned)f32_to_bf16(a[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(b[0]) | ((unsigned)f32_to_bf16(b[1]) << 16);
+    o.z = (unsigned)f32_to_bf16(c[0]) | ((unsigned)f32_to_bf16(c[1]) << 16);
+    o.w = (unsigned)f32_to_bf16(d[0]) | ((unsigned)f32_to_bf16(d[1]) << 16);
+    *(uint4*)(act + i * 8) = o;
+}
+// dh <- dh * GELU'(pre) in place (bf16), column sums of the result per row slab -> partial [nslab][n]
+__global__ __launch_bounds__(256) void dgelu_mul_colsum_bf16_kernel(bf16_t* dh, const bf16_t* pre, int64_t rows, int n, int64_t rows_per_block, float* partial) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (col >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0; r < r1; ++r) {
+        const uint2 g = *(const uint2*)(dh + r * n + col), h = *(const uint2*)(pre + r * n + col);
+        const f32x4 v = gelu_grad_mul4(f32x4{__uint_as_float(g.x << 16), __uint_as_float(g.x & 0xffff0000u), __uint_as_float(g.y << 16),
+                                             __uint_as_float(g.y & 0xffff0000u)}, h.x, h.y);
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *(uint2*)(dh + r * n + col) = o;
+        s[0] += __uint_as_float(o.x << 16); s[1] += __uint_as_float(o.x & 0xffff0000u);
+        s[2] += __uint_as_float(o.y << 16); s[3] += __uint_as_float(o.y & 0xffff0000u);
+    }
+    *(f32x4*)(partial + (int64_t)blockIdx.y * n + col) = s;
+}
+
+}  // namespace
+
+// un-fused GELU pieces (A/B experiment against the GEMM epilogues; bf16 only)
+int sc_gelu_fwd_bf16(const void* pre, void* act, int64_t n_elems, hipStream_t st) {
+    SC_REQUIRE(pre && act && n_elems > 0 && n_elems % 8 == 0, SC_ERR_ARG, "sc_gelu_fwd_bf16: bad argument");
+    hipLaunchKernelGGL(gelu_fwd_bf16_kernel, dim3((unsigned)sc_cdiv(n_elems / 8, 256)), dim3(256), 0, st, (const bf16_t*)pre, (bf16_t*)act, n_elems / 8);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+int sc_dgelu_mul_colsum_bf16(void* dh, const void* pre, int64_t rows, int64_t n, float* colsum, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    SC_REQUIRE(dh && pre && colsum && ws && rows > 0 && n > 0 && n % 4 == 0, SC_ERR_ARG, "sc_dgelu_mul_colsum_bf16: bad argument");
+    const int slabs = (int)min((int64_t)(n <= 1024 ? RED_MAX_BLOCKS : RED_MAX_BLOCKS / 3), sc_cdiv(rows, 32));
+    SC_REQUIRE(ws_bytes >= (size_t)slabs * n * sizeof(float), SC_ERR_WORKSPACE, "sc_dgelu_mul_colsum_bf16: workspace too small");
+    const int64_t rpb = sc_cdiv(rows, slabs);
+    const int nslab = (int)sc_cdiv(rows, rpb);
+    hipLaunchKernelGGL(dgelu_mul_colsum_bf16_kernel, dim3((unsigned)sc_cdiv(n, 1024), nslab), dim3(256), 0, st, (bf16_t*)dh, (const bf16_t*)pre, rows, (int)n, rpb,
+                       (float*)ws);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 32)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, colsum, (float*)nullptr,
+                       (float*)nullptr, accumulate);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, const float* gamma, const float* beta, void* y, int dtype,
