@@ -46,6 +46,7 @@ struct GemmBf16Params {
     float* cs_out;             // TN: optional column sums of A over r, cs_out[m] = cs_beta * cs_out[m] + sum_r A[r][m]  (bias gradient)
     float* cs_partial;         // TN: [splits][M] partial column sums when the contraction is split
     float cs_beta;
+    int group_m, group_n;      // NT 256x256: tile-walk cell (row tiles x column tiles an XCD's workgroups cover at a time)
     EpiParams epi;
 };
 
@@ -435,11 +436,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int band = tile / (B_GROUP_M * p.tiles_n), r_band = tile - band * (B_GROUP_M * p.tiles_n);
-    const int rows = min(B_GROUP_M, p.tiles_m - band * B_GROUP_M);
-    const int cell = r_band / (rows * B_GROUP_N), r_cell = r_band - cell * (rows * B_GROUP_N);
-    const int gw = min(B_GROUP_N, p.tiles_n - cell * B_GROUP_N);
-    const int m0 = (band * B_GROUP_M + r_cell / gw) * B_M, n0 = (cell * B_GROUP_N + r_cell % gw) * B_N;
+    const int GM = p.group_m, GN = p.group_n;
+    const int band = tile / (GM * p.tiles_n), r_band = tile - band * (GM * p.tiles_n);
+    const int rows = min(GM, p.tiles_m - band * GM);
+    const int cell = r_band / (rows * GN), r_cell = r_band - cell * (rows * GN);
+    const int gw = min(GN, p.tiles_n - cell * GN);
+    const int m0 = (band * GM + r_cell / gw) * B_M, n0 = (cell * GN + r_cell % gw) * B_N;
 
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
@@ -1471,6 +1473,9 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                     if (tm_main > 0 && rows_rem > 0 && (double)full + 0.55 * (double)rounds_rem < (double)(full + 1) - 0.1) m_main = tm_main * B_M;
                 }
             }
+            static const int g_m = [] { const char* e = getenv("SC_GEMM_NT_GROUP_M"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_M; }();   // A/B knobs
+            static const int g_n = [] { const char* e = getenv("SC_GEMM_NT_GROUP_N"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_N; }();
+            p.group_m = g_m; p.group_n = g_n;
             p.M = (int)m_main;
             p.tiles_m = (int)sc_cdiv(m_main, B_M); p.tiles_n = (int)tn_b;
             const unsigned gridb = (unsigned)(p.tiles_m * p.tiles_n);
