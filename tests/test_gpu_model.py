@@ -255,6 +255,37 @@ def test_c1_vit_b32_batch32_step_parity_fp32(pkg):
     assert abs(got - first[2]) <= 2e-2 * abs(first[2]), (got, first[2])
 
 
+@pytest.mark.parametrize("experiment,epoch", [("experiment_6-", 0), ("experiment_6-", 1), ("experiment_10-", 1), ("experiment_2-", 0)])
+def test_real_size_loss_stacks_step_parity_fp32(pkg, experiment, epoch):
+    """The other BASELINE loss stacks on the real ViT-B/32 at batch 32, fp32 path against the oracle's CPU step (1e-4 relative per
+    step, two steps): experiment 6 in its sparsification-only first epoch and in its main phase (anchor + lalign + lunif(centroids)),
+    experiment 10's ALPHA / BETA schedules (config 5's loss on config 1's model), experiment 2 (anchor, fixed temperature)."""
+    from conftest import load_json
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if experiment in k][0]]
+    cfg = finalize_config(raw, 0, {"model": "ViT-B-32", "batch_size": 32, "precision": "fp32"})
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = create_model("ViT-B-32", seed=7)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    cpu = CpuTrainer(cfg, 10, model=ref)
+    model = pkg.ClipModel("ViT-B-32", device=DEV, precision="fp32")
+    model.load_state_dict(sd)
+    gpu = Trainer(cfg, DEV, 10, model=model)
+    cpu.epoch = gpu.epoch = epoch
+    for k in range(2):
+        images_np, tokens_np = synthetic_batch(700 + k, 32, ref.cfg)
+        images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+        want = cpu.step(images, tokens).item()
+        got = gpu.step(images.to(DEV), tokens.to(DEV)).item()
+        assert abs(got - want) <= 1e-4 * abs(want), (experiment, epoch, k, got, want)
+    del model, gpu
+    torch.cuda.empty_cache()
+
+
 def test_full_size_step_properties_bf16(pkg):
     """BASELINE size (ViT-B/32, local batch 1024, bf16, experiment-6 loss stack, four concurrent streams): size-independent
     properties instead of an oracle the CPU could not finish - (1) two trainers from the same seed produce BIT-IDENTICAL losses
