@@ -286,6 +286,36 @@ def test_real_size_loss_stacks_step_parity_fp32(pkg, experiment, epoch):
     torch.cuda.empty_cache()
 
 
+def test_c5_vit_l14_real_size_step_parity_fp32(pkg):
+    """BASELINE config #5's real model (ViT-L/14, 428 M parameters, 257 image tokens) with its loss stack (experiment 10) at batch 4:
+    two training steps on the fp32 path against the oracle's CPU step, 1e-4 relative per step."""
+    from conftest import load_json
+    from oracle.clip_model import create_model, synthetic_batch
+    from oracle.train_step import CpuTrainer
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if "experiment_10-" in k][0]]
+    cfg = finalize_config(raw, 0, {"model": "ViT-L-14", "batch_size": 4, "precision": "fp32"})
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = create_model("ViT-L-14", seed=11)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    cpu = CpuTrainer(cfg, 10, model=ref)
+    model = pkg.ClipModel("ViT-L-14", device=DEV, precision="fp32")
+    model.load_state_dict(sd)
+    del sd
+    gpu = Trainer(cfg, DEV, 10, model=model)
+    cpu.epoch = gpu.epoch = 1
+    for k in range(2):
+        images_np, tokens_np = synthetic_batch(900 + k, 4, ref.cfg)
+        images, tokens = torch.tensor(images_np), torch.tensor(tokens_np)
+        want = cpu.step(images, tokens).item()
+        got = gpu.step(images.to(DEV), tokens.to(DEV)).item()
+        assert abs(got - want) <= 1e-4 * abs(want), (k, got, want)
+    del model, gpu
+    torch.cuda.empty_cache()
+
+
 def test_full_size_step_properties_bf16(pkg):
     """BASELINE size (ViT-B/32, local batch 1024, bf16, experiment-6 loss stack, four concurrent streams): size-independent
     properties instead of an oracle the CPU could not finish - (1) two trainers from the same seed produce BIT-IDENTICAL losses
