@@ -27,6 +27,10 @@ bool use_mfma() {
     return on;
 }
 // SC_ATTENTION=wave: the backward at seq <= 64 on the one-wave-per-head kernel instead of one workgroup per head (A/B runs)
+bool short_recompute() {
+    static const bool on = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
+    return on;
+}
 bool wave_per_head() {
     static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return e && e[0] == 'w'; }();
     return on;
@@ -280,7 +284,7 @@ extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t b
     SC_REQUIRE(qkv && out, SC_ERR_ARG, "sc_attention_fwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
         // forward, seq <= 80: one wave per head measured faster (81 / 86 us vs 85 / 112 us at the step's two shapes)
-        int rc = sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
+        int rc = short_recompute() ? 1 : sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc == 1) rc = sc_attention_long_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
         if (rc != 1) return rc;
     }
@@ -309,7 +313,7 @@ int attention_bwd_impl(const void* qkv, const void* d_out, void* d_qkv, int dtyp
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
         // backward: one workgroup per head wins at seq <= 64 (262 vs 303 us, S = 50), one wave per head at 64 < seq <= 80 (286 vs 341 us, S = 77)
-        int rc = (wave_per_head() || seq > 64) ? sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream) : 1;
+        int rc = short_recompute() ? 1 : (wave_per_head() || seq > 64) ? sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream) : 1;
         if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream);
         if (rc != 1) {
             if (cs_done) *cs_done = rc == SC_OK && cs_part != nullptr;

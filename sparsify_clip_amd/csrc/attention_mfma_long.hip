@@ -5,6 +5,7 @@
 // query tiles (and, in the backward's second pass, the key tiles) between them.  K and V fragments are read from LDS on
 // demand instead of being kept in registers (17 key tiles do not fit).
 #include "attention_mfma_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -276,6 +277,283 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, long sequences
+// Two sweeps over the key tiles per query tile (row max; then probabilities, row sum and P V per pair of key tiles, with the
+// score product recomputed) instead of NT score tiles held in registers and fully unrolled loops: ~100 VGPRs, 8 waves per
+// workgroup and two workgroups (78 KiB of K / V images each) per CU.
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, float scale) {
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    constexpr int IMG = NT * 16 * LDR;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_f2[];
+    bf16_t* Ks = lds_f2;
+    bf16_t* Vs = Ks + IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Vs, qb + 2 * W, ld, S, NT * 16, tid, 64 * NW);
+    __syncthreads();
+    const int g = lane >> 4, c16 = lane & 15;
+    const int n_t = (S + 15) >> 4;
+    for (int it = wave; it < n_t; it += NW) {
+        const bf16x8 q0 = row_frag_global(qb, ld, it, 0, lane, S), q1 = row_frag_global(qb, ld, it, 1, lane, S);
+        const int i = it * 16 + c16;
+        const int jt_end = CAUSAL ? min(n_t, it + 1) : n_t;
+        auto scores = [&](int jt) -> f32x4 {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
+            a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const bool ok = j < S && (!CAUSAL || j <= i);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+            }
+            return a;
+        };
+        float m = -INFINITY;
+        for (int jt = 0; jt < jt_end; ++jt) {
+            const f32x4 a = scores(jt);
+            m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+        }
+        m = group_max(m);
+        float l = 0.f;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < KS; ++s) {
+            if (2 * s >= jt_end) break;
+            f32x4 pr[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jt = 2 * s + u;
+                pr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jt >= jt_end) continue;
+                const f32x4 a = scores(jt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr[u][r] = __expf(a[r] - m);   // exp(-inf) = 0 for masked keys
+                    l += pr[u][r];
+                }
+            }
+            const bf16x8 pf = pack_frag(pr[0], pr[1]);
+            const bool hi_valid = !(ODD && s == KS - 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vt = hi_valid ? tr_frag<true>(Vs, s, 16 * dt, lane) : tr_frag<false>(Vs, s, 16 * dt, lane);
+                o[dt] = MFMA16(vt, pf, o[dt]);
+            }
+        }
+        l = group_sum(l);
+        const float inv = 1.0f / l;
+        if (i < S) {
+            bf16_t* op = out + ((int64_t)b * S + i) * W + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(op + 16 * dt, o[dt] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, long sequences
+// Same two passes as above, but pass 1 does not keep the scores and dP of all NT key tiles of a query tile in registers (140
+// VGPRs at NT = 17, which holds the kernel above to one wave per SIMD and 6.1 ms per ViT-L/14 layer): it sweeps the key tiles
+// three times - row max; row sum and delta = sum_j p_ij dp_ij; dQ - recomputing the two 16x16 MFMA products per key tile each
+// time (MFMA work is negligible here).  V is staged in LDS as a fourth image (4 x 272 x 144 B + statistics = 156 KiB), so
+// every fragment comes from LDS and the register budget allows NW = 16 waves per workgroup (4 per SIMD).
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale,
+                                                                         float* cs_part /* [batch][3 W] or null */) {
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    constexpr int IMG = NT * 16 * LDR;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_b2[];
+    bf16_t* Ks = lds_b2;
+    bf16_t* Qs = Ks + IMG;
+    bf16_t* Os = Qs + IMG;                  // dO
+    bf16_t* Vs = Os + IMG;
+    float* st_m = (float*)(Vs + IMG);
+    float* st_il = st_m + NT * 16;
+    float* st_dl = st_il + NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
+    bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
+    stage_head_block(Qs, qb, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Vs, qb + 2 * W, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Os, dob, W, S, NT * 16, tid, 64 * NW);
+    __syncthreads();
+    const int g = lane >> 4, c16 = lane & 15;
+    const int n_t = (S + 15) >> 4;
+
+    f32x4 csq[4], csk[4], csv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) csq[dt] = csk[dt] = csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---------------- pass 1: lane = query row i
+    for (int it = wave; it < n_t; it += NW) {
+        const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
+        const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
+        const int i = it * 16 + c16;
+        const int jt_end = CAUSAL ? min(n_t, it + 1) : n_t;   // key tiles past the diagonal are masked out entirely
+        auto scores = [&](int jt) -> f32x4 {                  // scaled, -inf where masked
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
+            a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const bool ok = j < S && (!CAUSAL || j <= i);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+            }
+            return a;
+        };
+        auto dprobs = [&](int jt) -> f32x4 {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = MFMA16(row_frag_lds(Vs, jt, 0, lane), g0, d);
+            d = MFMA16(row_frag_lds(Vs, jt, 1, lane), g1, d);
+            return d;
+        };
+        float m = -INFINITY;
+        for (int jt = 0; jt < jt_end; ++jt) {
+            const f32x4 a = scores(jt);
+            m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+        }
+        m = group_max(m);
+        float l = 0.f, num = 0.f;
+        for (int jt = 0; jt < jt_end; ++jt) {
+            const f32x4 a = scores(jt), d = dprobs(jt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(a[r] - m);   // exp(-inf) = 0 for masked keys
+                l += p;
+                num += p * d[r];
+            }
+        }
+        l = group_sum(l);
+        const float inv = 1.0f / l;
+        const float delta = group_sum(num) * inv;
+        if (g == 0) {
+            const bool live = i < S;
+            st_m[i] = live ? m : 0.f;
+            st_il[i] = live ? inv : 0.f;
+            st_dl[i] = live ? delta : 0.f;
+        }
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < KS; ++s) {
+            if (2 * s >= jt_end) break;
+            f32x4 ds[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jt = 2 * s + u;
+                ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jt >= jt_end) continue;
+                const f32x4 a = scores(jt), d = dprobs(jt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[u][r] = __expf(a[r] - m) * inv * (d[r] - delta) * scale;
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+            const bool hi_valid = !(ODD && s == KS - 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kt = hi_valid ? tr_frag<true>(Ks, s, 16 * dt, lane) : tr_frag<false>(Ks, s, 16 * dt, lane);
+                dq[dt] = MFMA16(kt, dsf, dq[dt]);
+            }
+        }
+        if (i < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
+        }
+        if (cs_part) cs_add(csq, dq, i < S);
+    }
+    // tiles of padding queries (none when n_t == NT) must read as "no contribution" in pass 2
+    for (int i = n_t * 16 + tid; i < NT * 16; i += 64 * NW) st_m[i] = st_il[i] = st_dl[i] = 0.f;
+    __syncthreads();   // every query tile's statistics are in LDS
+
+    // ---------------- pass 2: lane = key row j
+    for (int jt = wave; jt < n_t; jt += NW) {
+        const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
+        const bf16x8 v0 = row_frag_lds(Vs, jt, 0, lane), v1 = row_frag_lds(Vs, jt, 1, lane);
+        const int j = jt * 16 + c16;
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < KS; ++s) {   // a run-time loop: unrolled over all 9 k-steps the compiler keeps hundreds of values live
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int it = 2 * s + u;
+                if (ODD && it >= NT) continue;
+                if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
+                a = MFMA16(row_frag_lds(Qs, it, 1, lane), k1, a);
+                d = MFMA16(row_frag_lds(Os, it, 0, lane), v0, d);
+                d = MFMA16(row_frag_lds(Os, it, 1, lane), v1, d);
+                const f32x4 mm = *(const f32x4*)(st_m + it * 16 + 4 * g), il = *(const f32x4*)(st_il + it * 16 + 4 * g),
+                            dl = *(const f32x4*)(st_dl + it * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + 4 * g + r;
+                    const bool ok = i < S && j < S && (!CAUSAL || j <= i);
+                    const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
+                    pt[u][r] = p;
+                    dst[u][r] = p * (d[r] - dl[r]) * scale;
+                }
+            }
+            if (CAUSAL && 2 * s + 1 < jt) continue;
+            const bf16x8 pf = pack_frag(pt[0], pt[1]), dsf = pack_frag(dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bool hi_valid = !(ODD && s == KS - 1);
+                const bf16x8 ot = hi_valid ? tr_frag<true>(Os, s, 16 * dt, lane) : tr_frag<false>(Os, s, 16 * dt, lane);
+                const bf16x8 qt = hi_valid ? tr_frag<true>(Qs, s, 16 * dt, lane) : tr_frag<false>(Qs, s, 16 * dt, lane);
+                dv[dt] = MFMA16(ot, pf, dv[dt]);
+                dk[dt] = MFMA16(qt, dsf, dk[dt]);
+            }
+        }
+        if (j < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + W + 16 * dt + 4 * g, dk[dt]);
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + 2 * W + 16 * dt + 4 * g, dv[dt]);
+            }
+        }
+        if (cs_part) { cs_add(csk, dk, j < S); cs_add(csv, dv, j < S); }
+    }
+    if (cs_part) {   // per-wave sums over its tiles -> LDS -> the head's 192 columns for image b, waves added in a fixed order
+        cs_rows(csq); cs_rows(csk); cs_rows(csv);
+        __syncthreads();                       // the LDS images are dead
+        float* red = (float*)lds_b2;           // [NW][192]
+        if (c16 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(f32x4*)(red + wave * 192 + 16 * dt + 4 * g) = csq[dt];
+                *(f32x4*)(red + wave * 192 + 64 + 16 * dt + 4 * g) = csk[dt];
+                *(f32x4*)(red + wave * 192 + 128 + 16 * dt + 4 * g) = csv[dt];
+            }
+        }
+        __syncthreads();
+        if (tid < 192) {
+            float v = red[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) v += red[w2 * 192 + tid];
+            cs_part[(int64_t)b * 3 * W + (tid >> 6) * W + h * HD + (tid & 63)] = v;
+        }
+    }
+}
+
 template <typename K>
 int reserve_lds(K kernel, size_t bytes) {
     if (bytes > 65536) {
@@ -319,6 +597,39 @@ int launch_bwd_block(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
     return SC_OK;
 }
 
+template <int NT, int NW>
+int launch_fwd_long2(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+    const size_t lds = (size_t)2 * NT * 16 * LDR * sizeof(bf16_t);
+    const dim3 grid((unsigned)(batch * heads));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_fwd_long2_kernel<NT, true, NW>, lds));
+        hipLaunchKernelGGL((attn_fwd_long2_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+    } else {
+        SC_TRY(reserve_lds(attn_fwd_long2_kernel<NT, false, NW>, lds));
+        hipLaunchKernelGGL((attn_fwd_long2_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+template <int NT, int NW>
+int launch_bwd_long2(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, float* cs_part,
+                     hipStream_t st) {
+    const size_t lds = ((size_t)4 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)3 * NT * 16 * sizeof(float);
+    const dim3 grid((unsigned)(batch * heads));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_bwd_long2_kernel<NT, true, NW>, lds));
+        hipLaunchKernelGGL((attn_bwd_long2_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
+                           (int)width, (int)heads, 0.125f, cs_part);
+    } else {
+        SC_TRY(reserve_lds(attn_bwd_long2_kernel<NT, false, NW>, lds));
+        hipLaunchKernelGGL((attn_bwd_long2_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
+                           (int)width, (int)heads, 0.125f, cs_part);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
 }  // namespace
 
 // bf16, one workgroup per head, one wave per 16-row tile of the head where that fits (seq <= 64: 4 waves, <= 80: 5 waves) and
@@ -328,18 +639,28 @@ int launch_bwd_block(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
 // Returns 1 when the shape is not covered.
 int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
     if (seq > NT_LONG * 16) return 1;
+    static const bool short2 = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
+    if (short2 && seq <= 64) return launch_fwd_long2<4, 4>(qkv, out, batch, seq, width, heads, causal, st);
+    if (short2 && seq <= 80) return launch_fwd_long2<5, 5>(qkv, out, batch, seq, width, heads, causal, st);
     if (seq <= 64) return launch_fwd_block<4, 4>(qkv, out, batch, seq, width, heads, causal, st);
     if (seq <= 80) return launch_fwd_block<5, 5>(qkv, out, batch, seq, width, heads, causal, st);
-    return launch_fwd_block<NT_LONG, 4>(qkv, out, batch, seq, width, heads, causal, st);
+    static const bool old_long = [] { const char* e = getenv("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variants (A/B)
+    if (old_long) return launch_fwd_block<NT_LONG, 4>(qkv, out, batch, seq, width, heads, causal, st);
+    return launch_fwd_long2<NT_LONG, 8>(qkv, out, batch, seq, width, heads, causal, st);
 }
 
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                           float* cs_part, hipStream_t st) {
     if (seq > NT_LONG * 16) return 1;
+    static const bool short2 = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();   // =2: recompute kernels for short sequences too (A/B)
+    if (short2 && seq <= 64) return launch_bwd_long2<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
+    if (short2 && seq <= 80) return launch_bwd_long2<5, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     if (seq <= 64) return launch_bwd_block<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     if (seq <= 80) return launch_bwd_block<5, 5>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     // 4 waves (one per SIMD, 512 registers each): the backward keeps the scores and dP of all 17 key tiles of a query tile in
     // registers; with 8 waves (256 registers) it spills ~400 VGPRs.  At ViT-L/14 scale this kernel is 35 % of the step
     // (6.1 ms per layer at local batch 512): a recompute-per-key-tile formulation is the next step for that model.
-    return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
+    static const bool old_long = [] { const char* e = getenv("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variant (A/B)
+    if (old_long) return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
+    return launch_bwd_long2<NT_LONG, 8>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
 }

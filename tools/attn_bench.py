@@ -13,7 +13,10 @@ def timed(fn, reps=7):
         s.record(); fn(); e.record(); torch.cuda.synchronize()
         ts.append(s.elapsed_time(e))
     return sorted(ts)[len(ts) // 2]
-for name, (b, s, w, h, causal) in {"image": (1024, 50, 768, 12, False), "text": (1024, 77, 512, 8, True)}.items():
+shapes = {"image": (1024, 50, 768, 12, False), "text": (1024, 77, 512, 8, True)}
+if os.environ.get("ATTN_L14"):
+    shapes = {"vit-l/14 image": (512, 257, 1024, 16, False)}
+for name, (b, s, w, h, causal) in shapes.items():
     qkv = torch.randn(b * s, 3 * w, device=dev).to(torch.bfloat16)
     do = torch.randn(b * s, w, device=dev).to(torch.bfloat16)
     out = ops.attention_fwd(qkv, b, s, h, causal)
