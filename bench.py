@@ -55,6 +55,8 @@ def parse():
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-batch", type=int, default=32)
+    p.add_argument("--simulate-dp", type=int, default=8, help="N = 1 only: after the timed region, time the step again with the loss head fed a "
+                   "global batch of simulate_dp x local_batch rows (filler rows for the absent ranks) = the per-GPU work of that DP job; 1 = off")
     return p.parse_args()
 
 
@@ -172,11 +174,37 @@ def cpu_baseline(cfg, model_name, batch):
             "sample": f"{n} full training steps of {model_name} fp32 at {batch} pairs/step (oracle/train_step.py, plain torch on the host cores)"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (torch.distributed.run on 127.0.0.1) and
+    relay rank 0's JSON line.  Decided before this process touches the GPU (no torch.cuda call, no library load); the parent
+    never initialises HIP and never exec()s - it only waits for the launcher and exits with its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    progress(f"--gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks as child processes (port {port})")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if proc.returncode == 0 and not lines:
+        progress("the ranks exited 0 but printed no JSON line")
+        return 1
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     from sparsify_clip_amd import dist as D
     rank, local_rank, world = D.init_process_group()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))   # ranks > devices only in the gloo rehearsal
     torch.cuda.set_device(device)
     from sparsify_clip_amd.data import synthetic_batch
@@ -215,10 +243,30 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, local batch {args.local_batch}/GPU, "
-                                  f"global batch {global_batch}, AdamW, random-init weights",
+                                  f"global batch {global_batch}, AdamW, random-init weights; weak scaling: N = 8 is the metric's global batch 8192 "
+                                  f"(8192 pairs on ONE GPU need ~280 GB of saved activations + weights: does not fit 288 GB, see dp_rank_equivalent)",
                       "global_batch": global_batch, "local_batch": args.local_batch, "parallelism": f"dp{world}"},
            "last_loss": last_loss,
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
+    if world == 1 and args.simulate_dp > 1:
+        # what ONE rank of a simulate_dp-GPU job computes per step (replicated global-batch loss head included; no collective)
+        D.simulate_world(args.simulate_dp)
+        trainer.step(*batches[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nsim = min(args.steps, 8)
+        for i in range(nsim):
+            trainer.step(*batches[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / nsim
+        D.simulate_world(1)
+        out["dp_rank_equivalent"] = {"simulated_world": args.simulate_dp, "loss_head_batch": args.simulate_dp * args.local_batch,
+                                     "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
+                                     "note": "compute of one rank of the DP job (global-batch loss head replicated), collectives excluded"}
+    if world > 1:
+        # the ranks part here: rank 0's roofline replay runs alone, nobody sits in a collective with a timeout meanwhile
+        tdist.barrier()
+        tdist.destroy_process_group()
     if rank == 0:
         if args.precision == "bf16":
             progress("roofline: replaying the step's NT GEMM launches under HIP events")
@@ -228,9 +276,6 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(cfg, args.model, args.cpu_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        tdist.barrier()
-        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -15,6 +15,8 @@
  *     synchronising; scalar results are written to device memory;
  *   - return 0 on success, negative SC_ERR_* for host-side argument errors, positive = hipError_t;
  *     sc_last_error() returns thread-local text; nothing is printed, nothing throws;
+ *   - the library keeps no device memory, streams or events between calls: whatever outlives a call (workspaces, the events of
+ *     sc_block_bwd_async) is created, passed in and destroyed by the caller, so calls are re-entrant across host threads;
  *   - reductions use fixed-order partials (no float atomics): results are bit-stable run to run.
  */
 #ifndef SPARSIFY_HIP_H
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3
 
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_SHAPE = -2, SC_ERR_DTYPE = -3, SC_ERR_ALIGN = -4,
        SC_ERR_WORKSPACE = -5, SC_ERR_NO_DEVICE = -6 };
@@ -216,9 +218,16 @@ typedef struct sc_block_desc {
     /* workspace of the weight-gradient side stream of sc_block_bwd_async (same size rule as ws); may be NULL otherwise */
     void* ws_side;
     size_t ws_side_bytes;
+    /* sc_block_bwd_async only: four caller-owned HIP events (sc_event_create) that order `stream` and `side_stream` inside the
+     * call.  The library keeps none of its own: descriptors used from different host threads or devices get different events;
+     * descriptors enqueued one after the other from ONE thread may share a set. */
+    void* events[4];
 } sc_block_desc;
 
 size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype);
+/* HIP events (hipEventDisableTiming) on the CURRENT device for sc_block_desc.events; the caller destroys them. */
+int sc_event_create(void** event_out /* host */);
+int sc_event_destroy(void* event);
 /* x_out = block(x_in)  (open_clip ResidualAttentionBlock.forward) */
 int sc_block_fwd(const sc_block_desc* d, void* stream);
 /* dx_in (fp32 [rows,W]) = (d block / d x_in)^T dx_out; parameter grads into g_*.  dx_out_t / dx_in_t are optional copies
@@ -226,7 +235,7 @@ int sc_block_fwd(const sc_block_desc* d, void* stream);
 int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream);
 /* Same, with the weight-gradient GEMMs (dW = dY^T X) and the bias column sums of d_h / d_qkv enqueued on `side_stream`: they are
  * off the critical path of the activation gradients, so they overlap the HBM-bound kernels of `stream` (LayerNorm, attention).
- * Ordering inside the call is by HIP events owned by the library; the CALLER must (a) make `stream` wait for the side work of an
+ * Ordering inside the call is by the caller-owned events d->events[0..3]; the CALLER must (a) make `stream` wait for the side work of an
  * earlier call before a later call reuses the same scratch buffers (d_h, d_qkv, d_res_t, dx_out_t/dx_in_t, ws_side) - i.e. give
  * consecutive blocks alternating scratch sets - and (b) join `side_stream` before reading the parameter gradients. */
 int sc_block_bwd_async(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream,

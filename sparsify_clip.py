@@ -3,9 +3,10 @@
 
     python sparsify_clip.py --config <yaml file | directory of yaml files> --device <gpu id>
 
-Every experiments_configs/*.yaml and ablatation_configs/*.yaml of the reference is accepted unchanged.  The shipped
-files all say model "RN50", batch 256; optional overrides select the ViT configurations of BASELINE.json without
-editing them.  Under torchrun (WORLD_SIZE > 1) the run is data-parallel over the node's GPUs and --device is
+Every experiments_configs/*.yaml and ablatation_configs/*.yaml of the reference is read unchanged, but all of them say
+model "RN50" (ModifiedResNet), which is not implemented natively: without `--model ViT-B-32` (or ViT-L-14) such a file
+is rejected at load time with a message naming that override.  The optional overrides select the ViT configurations and
+batch sizes of BASELINE.json without editing the files.  Under torchrun (WORLD_SIZE > 1) the run is data-parallel over the node's GPUs and --device is
 replaced by LOCAL_RANK.  The loss/schedule functions of the reference are importable from this module by name.
 """
 import argparse

@@ -45,7 +45,8 @@ class BlockDesc(ctypes.Structure):
                 [(n, ctypes.c_void_p) for n in _BLOCK_PTRS_1] +
                 [("accumulate", ctypes.c_int32), ("b_fc2_done", ctypes.c_int32)] +
                 [(n, ctypes.c_void_p) for n in _BLOCK_PTRS_2] +
-                [("ws_bytes", ctypes.c_size_t), ("g_below_b_fc2", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_size_t)])
+                [("ws_bytes", ctypes.c_size_t), ("g_below_b_fc2", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_size_t),
+                 ("events", ctypes.c_void_p * 4)])
 
 
 _CTYPES = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
@@ -104,6 +105,29 @@ class _Lib:
 
 
 LIB = _Lib()
+
+
+class EventSet:
+    """Four caller-owned HIP events for sc_block_desc.events (sc_block_bwd_async orders its two streams with them)."""
+
+    def __init__(self):
+        self.handles = []
+        for _ in range(4):
+            h = ctypes.c_void_p()
+            LIB.call("sc_event_create", ctypes.byref(h))
+            self.handles.append(h.value)
+
+    def bind(self, desc):
+        for i, h in enumerate(self.handles):
+            desc.events[i] = h
+
+    def __del__(self):
+        try:
+            for h in self.handles:
+                LIB.raw("sc_event_destroy")(ctypes.c_void_p(h))
+        except Exception:
+            pass
+        self.handles = []
 
 
 def ptr(t):

@@ -123,13 +123,6 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
 
 namespace {
 
-// HIP events that order the two streams inside one sc_block_bwd_async call (created once per process, never timed)
-hipEvent_t side_event(int which) {
-    static hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (!ev[which] && hipEventCreateWithFlags(&ev[which], hipEventDisableTiming) != hipSuccess) ev[which] = nullptr;
-    return ev[which];
-}
-
 int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, hipStream_t st, hipStream_t side) {
     SC_TRY(check_desc(d, "sc_block_bwd"));
     SC_REQUIRE(dx_out && dx_in, SC_ERR_ARG, "sc_block_bwd: null gradient buffer");
@@ -146,6 +139,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     // fp32 path: the GEMM operand of the weight gradients is dx_out itself, which the caller may overwrite in place -> one stream
     const bool two = side != nullptr && side != st && bf;
     if (two) SC_REQUIRE(d->ws_side && d->ws_side_bytes >= need, SC_ERR_WORKSPACE, "sc_block_bwd_async: ws_side missing or too small");
+    if (two) SC_REQUIRE(d->events[0] && d->events[1] && d->events[2] && d->events[3], SC_ERR_ARG, "sc_block_bwd_async: d->events[0..3] must be caller-owned HIP events (sc_event_create)");
     hipStream_t ss = two ? side : st;                 // stream of the weight-gradient work
     void* wsw = two ? d->ws_side : d->ws;
     const size_t wsw_bytes = two ? d->ws_side_bytes : d->ws_bytes;
@@ -154,8 +148,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     // "everything enqueued on st so far is visible to the side stream"
     auto publish = [&]() -> int {
         if (!two) return SC_OK;
-        hipEvent_t e = side_event(nev++ & 3);
-        if (!e) return sc_set_error(SC_ERR_ARG, "sc_block_bwd_async: cannot create a HIP event");
+        hipEvent_t e = (hipEvent_t)d->events[nev++ & 3];
         hipError_t rc = hipEventRecord(e, st);
         if (rc == hipSuccess) rc = hipStreamWaitEvent(ss, e, 0);
         return rc == hipSuccess ? SC_OK : sc_set_error((int)rc, "sc_block_bwd_async: event: %s", hipGetErrorString(rc));
@@ -236,6 +229,21 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
 }
 
 }  // namespace
+
+extern "C" int sc_event_create(void** event_out) {
+    SC_REQUIRE(event_out != nullptr, SC_ERR_ARG, "sc_event_create: null output");
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return sc_set_error((int)rc, "sc_event_create: %s", hipGetErrorString(rc));
+    *event_out = (void*)e;
+    return SC_OK;
+}
+
+extern "C" int sc_event_destroy(void* event) {
+    if (!event) return SC_OK;
+    const hipError_t rc = hipEventDestroy((hipEvent_t)event);
+    return rc == hipSuccess ? SC_OK : sc_set_error((int)rc, "sc_event_destroy: %s", hipGetErrorString(rc));
+}
 
 extern "C" int sc_block_bwd(const sc_block_desc* d, const float* dx_out, const void* dx_out_t, float* dx_in, void* dx_in_t, void* stream) {
     return block_bwd_impl(d, dx_out, dx_out_t, dx_in, dx_in_t, (hipStream_t)stream, nullptr);

@@ -617,278 +617,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     }
 }
 
-// ------------------------------------------------------------------------------------------------ NT, 256x128x32, two workgroups per CU on AGPRs
-// The 256x256 kernel above owns a whole CU, so its prologue (first LDS-DMA round trip) and its epilogue (accumulator read-back,
-// LDS slab, GELU / residual arithmetic, stores: ~12 us per tile against ~18 us of main loop at K = 768) run with the MFMA units
-// idle.  This kernel keeps the wave tile (128x64, accumulators in AGPRs a0..a127, same inline-assembly MFMA / LDS-read
-// statements) but a workgroup is 4 waves (2 x 2, one per SIMD) on a 256x128 tile with K-step 32: three 24-KiB stages = 72 KiB
-// of LDS and 256 registers per wave, so TWO workgroups share a CU and one's epilogue / prologue / LDS waits run under the
-// other's MFMAs - the overlap is the hardware's wave interleaving, no persistent scheduler needed.  64-byte LDS rows with the
-// slot swizzle of the 2-workgroup variant below (chunk c of row r at slot c ^ ((-(r >> 2)) & 3): conflict-free b128 reads).
-constexpr int PP_M = 256, PP_N = 128, PP_K = 32, PP_A = PP_M * 64, PP_STAGE = (PP_M + PP_N) * 64, PP_STAGES = 3;
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_pp_kernel(GemmBf16Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[PP_STAGES * PP_STAGE];   // 73728 B; the epilogue slabs (4 x 17408 B) reuse it
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int band = tile / (GROUP_M * p.tiles_n), r_band = tile - band * (GROUP_M * p.tiles_n);
-    const int rows = min(GROUP_M, p.tiles_m - band * GROUP_M);
-    const int cell = r_band / (rows * GROUP_N), r_cell = r_band - cell * (rows * GROUP_N);
-    const int gw = min(GROUP_N, p.tiles_n - cell * GROUP_N);
-    const int m0 = (band * GROUP_M + r_cell / gw) * PP_M, n0 = (cell * GROUP_N + r_cell % gw) * PP_N;
-
-    // staging: one wave instruction = 16 rows x 64 B; lane -> (row l >> 2, slot l & 3) holds chunk slot ^ f(row)
-    const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
-    const bf16_t* ga[4];
-    const bf16_t* gb[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ga[q] = p.A + (int64_t)min(m0 + wave * 64 + q * 16 + srow, p.M - 1) * p.lda + schunk * 8;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) gb[q] = p.B + (int64_t)min(n0 + wave * 32 + q * 16 + srow, p.N - 1) * p.ldb + schunk * 8;
-
-    asm volatile("" ::: SC_ACC_AGPRS);   // reserve the accumulator AGPRs in the kernel descriptor
-
-    const int nk = p.K / PP_K;
-    const int frow = lane & 15, fq = lane >> 4;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned fpos = (fq ^ ((-(frow >> 2)) & 3)) * 16;
-    const unsigned fa = lds0 + (wm * 128 + frow) * 64 + fpos, fb = lds0 + PP_A + (wn * 64 + frow) * 64 + fpos;
-
-#define PP_STAGE_LOAD(S, KT)                                                                          \
-    do {                                                                                              \
-        char* ab__ = smem + (S) * PP_STAGE + (wave * 64) * 64;                                        \
-        char* bb__ = smem + (S) * PP_STAGE + PP_A + (wave * 32) * 64;                                 \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(ga[q] + (KT) * PP_K, ab__ + q * 16 * 64); \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) glds16(gb[q] + (KT) * PP_K, bb__ + q * 16 * 64); \
-    } while (0)
-    // One K-tile: tile KT has landed when at most the 6 LDS-DMA instructions of tile KT+1 are outstanding; the barrier also retires
-    // every read of tile KT-1, whose stage receives tile KT+2.  The 12 fragment reads are not software-pipelined: while this wave
-    // waits for them the other workgroup's wave on the same SIMD issues its MFMAs.
-#define PP_BODY(S, KT)                                                                                \
-    do {                                                                                              \
-        if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                           \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-        __builtin_amdgcn_s_barrier();                                                                 \
-        if ((KT) + 2 < nk) PP_STAGE_LOAD(((S) + 2) % PP_STAGES, (KT) + 2);                            \
-        ntb_read<(S) * PP_STAGE + 0 * 1024>(b[0], fb); ntb_read<(S) * PP_STAGE + 1 * 1024>(b[1], fb); \
-        ntb_read<(S) * PP_STAGE + 2 * 1024>(b[2], fb); ntb_read<(S) * PP_STAGE + 3 * 1024>(b[3], fb); \
-        ntb_read<(S) * PP_STAGE + 0 * 1024>(a[0], fa); ntb_read<(S) * PP_STAGE + 1 * 1024>(a[1], fa); \
-        ntb_read<(S) * PP_STAGE + 2 * 1024>(a[2], fa); ntb_read<(S) * PP_STAGE + 3 * 1024>(a[3], fa); \
-        ntb_read<(S) * PP_STAGE + 4 * 1024>(a[4], fa); ntb_read<(S) * PP_STAGE + 5 * 1024>(a[5], fa); \
-        ntb_read<(S) * PP_STAGE + 6 * 1024>(a[6], fa); ntb_read<(S) * PP_STAGE + 7 * 1024>(a[7], fa); \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
-        ntb_substep<0, false>(a, b, b, 0u, 0u);                                                       \
-    } while (0)
-
-    bf16x8 a[8], b[4];
-    PP_STAGE_LOAD(0, 0);
-    if (nk > 1) PP_STAGE_LOAD(1, 1);
-    ntb_zero<0>();
-    int kt = 0;
-    for (; kt + 3 <= nk; kt += 3) {
-        PP_BODY(0, kt);
-        PP_BODY(1, kt + 1);
-        PP_BODY(2, kt + 2);
-    }
-    if (kt < nk) {
-        PP_BODY(0, kt);
-        if (kt + 1 < nk) PP_BODY(1, kt + 1);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
-#undef PP_BODY
-#undef PP_STAGE_LOAD
-
-    // Epilogue: as in the 256x128 kernel (per-wave 64x64 LDS slab, row-major 16-byte pieces), two passes of 64 rows per wave.
-    const EpiParams& e = p.epi;
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    const int n = n0 + wn * 64 + ecol;
-    const bool ncol_ok = n < p.N;
-    const int nn = ncol_ok ? n : 0;
-    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
-    const bool has_pre = e.dgelu_pre != nullptr, has_res = e.resid != nullptr, res_f32 = e.resid_dtype == SC_F32;
-    if (e.bias) { bias0 = *(const f32x4*)(e.bias + nn); bias1 = *(const f32x4*)(e.bias + nn + 4); }
-    __syncthreads();   // every wave is done reading the last K-tile
-    float* slab = (float*)smem + wave * (64 * 68);   // 4 x 17408 B <= 3 stages
-    // fused column sums of the stored output (bias gradient of the producing layer): per lane 8 columns over all of its rows
-    const bool do_cs = e.cs_partial != nullptr;
-    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int mw = m0 + wm * 128 + h * 64;
-        if (h == 0) ntb_to_slab<0, 0>(slab + frow * 68 + 4 * fq);
-        else ntb_to_slab<0, 1>(slab + frow * 68 + 4 * fq);
-        if (ncol_ok) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {   // 4 rows per lane at a time: their GELU' / residual operands are requested together
-            uint4 hpre[4];
-            f32x4 res0[4], res1[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int m = min(mw + (4 * g + it) * 8 + erow, p.M - 1);
-                const int64_t off = (int64_t)m * e.ld_aux + nn;
-                if (has_pre) hpre[it] = *(const uint4*)((const bf16_t*)e.dgelu_pre + off);
-                if (has_res) {
-                    if (res_f32) {
-                        res0[it] = *(const f32x4*)((const float*)e.resid + off);
-                        res1[it] = *(const f32x4*)((const float*)e.resid + off + 4);
-                    } else {
-                        res0[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off);
-                        res1[it] = io<bf16_t>::ld4((const bf16_t*)e.resid + off + 4);
-                    }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = (4 * g + it) * 8 + erow;
-                const int m = mw + row;
-                if (m >= p.M) continue;
-                f32x4 v0 = *(const f32x4*)(slab + row * 68 + ecol) * e.alpha + bias0;
-                f32x4 v1 = *(const f32x4*)(slab + row * 68 + ecol + 4) * e.alpha + bias1;
-                const int64_t off = (int64_t)m * e.ld_aux + n;
-                if (e.pre_out) {
-                    io<bf16_t>::st4((bf16_t*)e.pre_out + off, v0);
-                    io<bf16_t>::st4((bf16_t*)e.pre_out + off + 4, v1);
-                }
-                if (e.act == 1) {
-                    v0 = gelu_fast4(v0); v1 = gelu_fast4(v1);
-                }
-                if (has_pre) {
-                    const uint4 hh = hpre[it];
-                    v0 = gelu_grad_mul4(v0, hh.x, hh.y); v1 = gelu_grad_mul4(v1, hh.z, hh.w);
-                }
-                if (has_res) { v0 += res0[it]; v1 += res1[it]; }
-                if (OUT_F32) {
-                    float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-                    if (e.beta != 0.f) { v0 += *(const f32x4*)cp * e.beta; v1 += *(const f32x4*)(cp + 4) * e.beta; }
-                    *(f32x4*)cp = v0;
-                    *(f32x4*)(cp + 4) = v1;
-                    if (do_cs) { cs0 += v0; cs1 += v1; }
-                } else {
-                    uint4 u;
-                    u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
-                    u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
-                    u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
-                    u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
-                    *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
-                    if (do_cs) {   // the values as stored (bf16-rounded): identical to a pass over C
-                        cs0[0] += __uint_as_float(u.x << 16); cs0[1] += __uint_as_float(u.x & 0xffff0000u);
-                        cs0[2] += __uint_as_float(u.y << 16); cs0[3] += __uint_as_float(u.y & 0xffff0000u);
-                        cs1[0] += __uint_as_float(u.z << 16); cs1[1] += __uint_as_float(u.z & 0xffff0000u);
-                        cs1[2] += __uint_as_float(u.w << 16); cs1[3] += __uint_as_float(u.w & 0xffff0000u);
-                    }
-                }
-            }
-          }
-        }
-    }
-    if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per (row tile, wave row)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cs0[j] += __shfl_xor(cs0[j], 8, 64);  cs1[j] += __shfl_xor(cs1[j], 8, 64);
-            cs0[j] += __shfl_xor(cs0[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64);
-            cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
-        }
-        if (lane < 8 && ncol_ok) {
-            float* dst = e.cs_partial + (int64_t)((m0 / PP_M) * 2 + wm) * p.N + n;
-            *(f32x4*)dst = cs0;
-            *(f32x4*)(dst + 4) = cs1;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ NT, 256x128x32, 2 workgroups/CU
-// Same 256x128 tile and wave layout as the kernel above but K-step 32 and three 24-KiB stages (72 KiB): TWO workgroups fit a
-// CU (16 waves, <= 128 VGPRs), so one workgroup's prologue / epilogue (bias, GELU, residual, stores) runs under the other
-// one's MFMAs - the 144-KiB variant leaves the CU idle there.  64-byte LDS rows: chunk c of row r sits at slot
-// c ^ ((-(r >> 2)) & 3), which makes every ds_read_b128 lane group hit 16 distinct 16-B slots (conflict-free).
-constexpr int V3_KSTEP = 32, V3_STAGE = (T_M + T_N) * 64, V3_A = T_M * 64;
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_nt_v3_kernel(GemmBf16Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * V3_STAGE];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int band = tile / (GROUP_M * p.tiles_n), r_band = tile - band * (GROUP_M * p.tiles_n);
-    const int rows = min(GROUP_M, p.tiles_m - band * GROUP_M);
-    const int cell = r_band / (rows * GROUP_N), r_cell = r_band - cell * (rows * GROUP_N);
-    const int gw = min(GROUP_N, p.tiles_n - cell * GROUP_N);
-    const int m0 = (band * GROUP_M + r_cell / gw) * T_M, n0 = (cell * GROUP_N + r_cell % gw) * T_N;
-
-    // staging: one wave instruction = 16 rows x 64 B; lane -> (row l>>2, slot l&3) holds chunk slot ^ f(row)
-    const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
-    const bf16_t* ga0 = p.A + (int64_t)min(m0 + wave * 32 + srow, p.M - 1) * p.lda + schunk * 8;
-    const bf16_t* ga1 = p.A + (int64_t)min(m0 + wave * 32 + 16 + srow, p.M - 1) * p.lda + schunk * 8;
-    const bf16_t* gb0 = p.B + (int64_t)min(n0 + wave * 16 + srow, p.N - 1) * p.ldb + schunk * 8;
-#define V3_STAGE_LOAD(S, KT)                                                                          \
-    do {                                                                                              \
-        char* ab__ = smem + (S) * V3_STAGE + (wave * 32) * 64;                                        \
-        glds16(ga0 + (KT) * V3_KSTEP, ab__);                                                          \
-        glds16(ga1 + (KT) * V3_KSTEP, ab__ + 16 * 64);                                                \
-        glds16(gb0 + (KT) * V3_KSTEP, smem + (S) * V3_STAGE + V3_A + (wave * 16) * 64);               \
-    } while (0)
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / V3_KSTEP;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int fpos = (fq ^ ((-(frow >> 2)) & 3)) * 16;
-    const int a_off = (wm * 64 + frow) * 64 + fpos, b_off = V3_A + (wn * 64 + frow) * 64 + fpos;
-#define V3_BODY(S, KT)                                                                                \
-    do {                                                                                              \
-        if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                           \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-        __builtin_amdgcn_s_barrier();                                                                 \
-        if ((KT) + 2 < nk) V3_STAGE_LOAD(((S) + 2) % STAGES, (KT) + 2);                               \
-        const char* st__ = smem + (S) * V3_STAGE;                                                     \
-        bf16x8 af__[4], bf__[4];                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) af__[i] = *(const bf16x8*)(st__ + a_off + i * 16 * 64); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) bf__[i] = *(const bf16x8*)(st__ + b_off + i * 16 * 64); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf__[j], af__[i], acc[i][j], 0, 0, 0); \
-    } while (0)
-
-    V3_STAGE_LOAD(0, 0);
-    if (nk > 1) V3_STAGE_LOAD(1, 1);
-    for (int kt = 0; kt < nk; kt += STAGES) {
-        V3_BODY(0, kt);
-        if (kt + 1 < nk) V3_BODY(1, kt + 1);
-        if (kt + 2 < nk) V3_BODY(2, kt + 2);
-    }
-#undef V3_BODY
-#undef V3_STAGE_LOAD
-
-    // D[n][m]: lane holds m = ..+(lane&15), n = ..+4*(lane>>4)+reg : 8-byte (bf16) / 16-byte (fp32) pieces
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + 4 * fq;
-            if (n >= p.N) continue;
-            if (OUT_F32) {
-                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-                *(f32x4*)cp = epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, cp);
-            } else {
-                bf16_t* cp = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
-                io<bf16_t>::st4(cp, epi_vec4<bf16_t>(p.epi, acc[i][j], m, n, nullptr));
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ TN
 // LDS tile: [64 r][128 cols] bf16, 256-B rows.  32-B slot swizzle so that the 8 rows a 32-lane half touches in one
 // ds_read_b64_tr_b16 fall on 8 different 32-B slots of the 256-B bank row.
@@ -1045,158 +773,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
             const float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
             if (p.cs_partial) p.cs_partial[(int64_t)split * p.M + m] = v;
             else p.cs_out[m] = p.cs_beta != 0.f ? v + p.cs_beta * p.cs_out[m] : v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ TN, 256x128, 3-stage
-// Same pipeline as the NT 256x128 kernel (3 LDS stages, counted vmcnt, one barrier per 64-row step, LDS reads woven under
-// the MFMAs); a stage holds three [64 r][128 cols] images with 256-B rows (two for the 256 columns of A, one for B), all
-// with the 32-B slot swizzle of tn_swz, read back transposed by ds_read_b64_tr_b16.  The contraction is split over
-// workgroups so that tiles x splits fills the chip once (<= 256 workgroups, one per CU: no tail round).
-constexpr int TN_IMG = 16384;   // one [64][128] bf16 image
-
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(GemmBf16Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int id = xcd_remap(blockIdx.x, ntiles * p.splits);
-    const int split = id / ntiles, tile = id % ntiles;
-    const int m0 = (tile / p.tiles_n) * T_M, n0 = (tile % p.tiles_n) * T_N;
-    const int kt_begin = split * p.k_per_split;
-    const int nk_total = (p.K + KSTEP - 1) / KSTEP;
-    const int kt_end = min(nk_total, kt_begin + p.k_per_split);
-    const int nk = kt_end - kt_begin;
-
-    // staging: per image 16 wave instructions of 4 rows x 256 B; wave w takes instructions 2w and 2w+1 of every image
-    const int srow = lane >> 4;
-    int col_a0[2], col_a1[2], col_b[2], rowq[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = (wave * 2 + q) * 4 + srow;
-        const int c = (lane & 15) ^ tn_swz(r);
-        rowq[q] = r;
-        col_a0[q] = min(m0 + c * 8, p.M - 8);
-        col_a1[q] = min(m0 + 128 + c * 8, p.M - 8);
-        col_b[q] = min(n0 + c * 8, p.N - 8);
-    }
-#define TN256_STAGE(S, KT)                                                                                      \
-    do {                                                                                                        \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                         \
-            const int64_t gr__ = min((kt_begin + (KT)) * KSTEP + rowq[q], p.K - 1);                             \
-            char* dst__ = smem + (S) * STAGE_BYTES + (wave * 2 + q) * 1024;                                     \
-            glds16(p.A + gr__ * p.lda + col_a0[q], dst__);                                                      \
-            glds16(p.A + gr__ * p.lda + col_a1[q], dst__ + TN_IMG);                                             \
-            glds16(p.B + gr__ * p.ldb + col_b[q], dst__ + 2 * TN_IMG);                                          \
-        }                                                                                                       \
-    } while (0)
-    // rows past the contraction length contribute zero (their clamped loads fetched a valid row): executed by every wave
-    // between the barrier that publishes the stage and the first read, followed by its own barrier (last step only)
-#define TN256_ZERO_TAIL(S, KT)                                                                                  \
-    do {                                                                                                        \
-        const int valid__ = p.K - (kt_begin + (KT)) * KSTEP;                                                    \
-        if (valid__ < KSTEP) {                                                                                  \
-            for (int piece = t; piece < 3 * 1024; piece += 512) {                                               \
-                const int row = (piece & 1023) >> 4;                                                            \
-                if (row >= valid__) *(uint4*)(smem + (S) * STAGE_BYTES + piece * 16) = uint4{0u, 0u, 0u, 0u};   \
-            }                                                                                                   \
-            __syncthreads();                                                                                    \
-        }                                                                                                       \
-    } while (0)
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
-    const int swz = (q4 | ((g & 1) << 2)) << 1;
-    const int a_img = (wm >> 1) * TN_IMG, a_col = (wm & 1) * 64, b_col = wn * 64;
-    // fragments of k-substep SUB (0/1) of stage S: element e <-> row 32*SUB + 8g + e
-#define TN256_READ(S, SUB, AF, BF)                                                                              \
-    do {                                                                                                        \
-        const char* st__ = smem + (S) * STAGE_BYTES;                                                            \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                         \
-            const int row = 32 * (SUB) + 8 * g + 4 * h + q4;                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
-                const int ca = ((a_col + 16 * i) >> 3) + (pp >> 1), cb = ((b_col + 16 * i) >> 3) + (pp >> 1);   \
-                const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(st__ + a_img + row * 256 + ((ca ^ swz) << 4) + ((pp & 1) << 3))); \
-                const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(st__ + 2 * TN_IMG + row * 256 + ((cb ^ swz) << 4) + ((pp & 1) << 3))); \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) { AF[i][4 * h + e] = va[e]; BF[i][4 * h + e] = vb[e]; } \
-            }                                                                                                   \
-        }                                                                                                       \
-    } while (0)
-#define TN256_MMA(AF, BF)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j], AF[i], acc[i][j], 0, 0, 0)
-#define TN256_WEAVE()                                                                                           \
-    _Pragma("unroll") for (int g__ = 0; g__ < 16; ++g__) {                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
-    }
-#define TN256_BODY(S, KT)                                                                                       \
-    do {                                                                                                        \
-        TN256_READ(S, 1, a1, b1);                                                                               \
-        TN256_MMA(a0, b0);                                                                                      \
-        TN256_WEAVE();                                                                                          \
-        if ((KT) + 1 < nk) {                                                                                    \
-            if ((KT) + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                      \
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
-            __builtin_amdgcn_s_barrier();                                                                       \
-            if ((KT) + 3 < nk) TN256_STAGE(S, (KT) + 3);                                                        \
-            if ((KT) + 2 == nk) TN256_ZERO_TAIL(((S) + 1) % STAGES, (KT) + 1);                                  \
-            TN256_READ(((S) + 1) % STAGES, 0, a0, b0);                                                          \
-            TN256_MMA(a1, b1);                                                                                  \
-            TN256_WEAVE();                                                                                      \
-        } else {                                                                                                \
-            TN256_MMA(a1, b1);                                                                                  \
-        }                                                                                                       \
-    } while (0)
-
-    if (nk > 0) {
-        bf16x8 a0[4], b0[4], a1[4], b1[4];
-        TN256_STAGE(0, 0);
-        if (nk > 1) TN256_STAGE(1, 1);
-        if (nk > 2) TN256_STAGE(2, 2);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (nk == 1) TN256_ZERO_TAIL(0, 0);
-        TN256_READ(0, 0, a0, b0);
-        for (int kt = 0; kt < nk; kt += STAGES) {
-            TN256_BODY(0, kt);
-            if (kt + 1 < nk) TN256_BODY(1, kt + 1);
-            if (kt + 2 < nk) TN256_BODY(2, kt + 2);
-        }
-    }
-#undef TN256_BODY
-#undef TN256_WEAVE
-#undef TN256_MMA
-#undef TN256_READ
-#undef TN256_ZERO_TAIL
-#undef TN256_STAGE
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + i16;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + 4 * g;
-            if (n >= p.N) continue;
-            if (p.partial) {
-                *(f32x4*)(p.partial + ((int64_t)split * p.M + m) * p.N + n) = acc[i][j];
-            } else {
-                float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-                f32x4 v = acc[i][j] * p.epi.alpha;
-                if (p.epi.beta != 0.f) v += *(const f32x4*)cp * p.epi.beta;
-                *(f32x4*)cp = v;
-            }
         }
     }
 }
@@ -1385,11 +961,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
 }
 
 // TN kernel choice.  Default: the 256x256 AGPR kernel when the output has at least 6 such tiles and R % 64 == 0, otherwise the
-// 128x128 2-stage kernel at 2 workgroups/CU.  SC_GEMM_TN=128 forces the latter everywhere, SC_GEMM_TN=256 selects the older
-// 256x128 3-stage variant for calls without fused column sums (both kept for A/B runs).
-enum TnKind { TN_SMALL = 0, TN_256 = 1, TN_BIG = 2 };
+// 128x128 2-stage kernel at 2 workgroups/CU.  SC_GEMM_TN=128 forces the latter everywhere (run once by the test-suite).
+enum TnKind { TN_SMALL = 0, TN_BIG = 2 };
 int tn_env() {
-    static const int v = [] { const char* e = getenv("SC_GEMM_TN"); return !e ? 0 : (e[0] == '1' ? 128 : (e[0] == '2' ? 256 : 0)); }();
+    static const int v = [] { const char* e = getenv("SC_GEMM_TN"); return (e && e[0] == '1') ? 128 : 0; }();
     return v;
 }
 void tn_plan_small(int64_t m, int64_t n, int64_t r, int& kind, int& splits) {
@@ -1408,9 +983,6 @@ void tn_plan(int64_t m, int64_t n, int64_t r, bool colsum, int& kind, int& split
     if (tn_env() == 0 && r % KSTEP == 0 && tiles_big >= 6) {
         kind = TN_BIG;
         s = 256 / tiles_big;       // one round of at most 256 workgroups
-    } else if (tn_env() == 256 && !colsum) {
-        kind = TN_256;
-        s = 256 / (sc_cdiv(m, T_M) * sc_cdiv(n, T_N));
     } else {
         kind = TN_SMALL;
         s = sc_cdiv(768, sc_cdiv(m, TILE) * sc_cdiv(n, TILE));
@@ -1453,7 +1025,7 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     } else {
         p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
         const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
-        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '3') ? 3 : (e && e[0] == '2') ? 2 : (e && e[0] == 'p') ? 4 : 0; }();   // SC_GEMM_NT=3: 2 workgroups/CU variant, =2: 256x128 everywhere
+        static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '2') ? 2 : 0; }();   // SC_GEMM_NT=2: 256x128 kernel everywhere (run once by the test-suite)
         static const int big_min_n = [] { const char* e = getenv("SC_GEMM_NT_BIG_MINN"); return e ? atoi(e) : 512; }();   // A/B knob (1536: wide outputs only)
         if (variant == 0 && n >= big_min_n && m >= 4096) {
             // Tile-count quantisation: all tiles cost the same, so ceil(tiles / 256) rounds are paid even when the last one is
@@ -1500,19 +1072,6 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                 if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid2), dim3(512), 0, stream, q);
                 else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid2), dim3(512), 0, stream, q);
             }
-        } else if (variant == 4 && k % PP_K == 0) {
-            p.tiles_m = (int)sc_cdiv(m, PP_M); p.tiles_n = (int)sc_cdiv(n, PP_N);
-            const unsigned gridp = (unsigned)(p.tiles_m * p.tiles_n);
-            if (epi.colsum && epi.colsum_ws_bytes >= (size_t)2 * p.tiles_m * n * sizeof(float) && sc_aligned(epi.colsum_ws, 16)) {
-                p.epi.cs_partial = (float*)epi.colsum_ws;
-                cs_fused = true;
-                cs_rows_done = m;
-            }
-            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3(gridp), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3(gridp), dim3(256), 0, stream, p);
-        } else if (variant == 3) {
-            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
-            else hipLaunchKernelGGL(gemm_bf16_nt_v3_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
         } else {
             if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
@@ -1556,7 +1115,7 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     if (kind == TN_BIG && colsum_a && (colsum_beta != 0.f && colsum_beta != 1.f)) kind = TN_SMALL;   // the separate pass only knows overwrite / accumulate
     if (kind == TN_BIG && colsum_a && ws_bytes < (size_t)1024 * m * sizeof(float)) kind = TN_SMALL;    // its partials reuse ws
     if (kind == TN_SMALL) { int k2; tn_plan_small(m, n, r, k2, p.splits); }
-    const int tm = kind == TN_SMALL ? TILE : (kind == TN_BIG ? B_M : T_M), tn = kind == TN_SMALL ? TILE : (kind == TN_BIG ? B_N : T_N);
+    const int tm = kind == TN_SMALL ? TILE : B_M, tn = kind == TN_SMALL ? TILE : B_N;
     p.tiles_m = (int)sc_cdiv(m, tm); p.tiles_n = (int)sc_cdiv(n, tn);
     p.cs_out = colsum_a; p.cs_partial = nullptr; p.cs_beta = colsum_beta;
     const int64_t nk = sc_cdiv(r, KSTEP);
@@ -1573,8 +1132,7 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n * p.splits);
     if (kind == TN_BIG) { p.cs_out = nullptr; p.cs_partial = nullptr; }   // column sums: separate pass below
     if (kind == TN_SMALL) hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
-    else if (kind == TN_BIG) hipLaunchKernelGGL(gemm_bf16_tn_big_kernel, dim3(grid), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_bf16_tn256_kernel, dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_tn_big_kernel, dim3(grid), dim3(512), 0, stream, p);
     SC_CHECK_LAUNCH();
     if (p.splits > 1) {
         const int64_t mn = m * n;

@@ -20,10 +20,12 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_process_group(backend=None):
-    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  No-op at world size 1."""
+def init_process_group(backend=None, force=False):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  No-op at world size 1 unless
+    `force` (a world-1 group: every collective below then really goes through the backend - how the RCCL path is exercised on
+    a one-GPU box, tests/test_gpu_dp.py)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,6 +44,11 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def active():
+    """True when a process group exists: the collectives run (also at world size 1, see init_process_group(force=True))."""
+    return dist.is_initialized()
+
+
 def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
@@ -54,32 +61,75 @@ def shard_bounds(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+_gather_bufs = {}
+_sim = {"world": 1, "fill": {}}
+
+
+def simulate_world(w: int):
+    """Bench-only: with no process group, make the gather return a [w*Bl, E] batch whose first Bl rows are this rank's and whose
+    other rows are fixed unit-norm filler, so that ONE GPU runs the loss head at the global batch of a w-rank job (what every rank
+    of that job computes).  No collective is simulated.  w = 1 switches it off."""
+    _sim["world"] = int(w)
+
+
+def _sim_gather(local: torch.Tensor, which: int):
+    bl, e = local.shape
+    w = _sim["world"]
+    key = (bl, e, w, which, str(local.device))
+    full = _sim["fill"].get(key)
+    if full is None:
+        g = torch.Generator(device="cpu").manual_seed(977 + which)
+        rows = torch.nn.functional.normalize(torch.randn(w * bl, e, generator=g), dim=-1)
+        full = _sim["fill"][key] = rows.to(local.device)
+    full[:bl].copy_(local)
+    return full
+
+
+
+def gather_send_buffer(bl: int, e: int, device):
+    """The rank's fused send buffer [2, Bl, E] (image rows, then text rows): the L2-normalisation kernels write their outputs
+    straight into its two halves, so the exchange needs no torch.cat."""
+    key = (bl, e, str(device), world_size())
+    buf = _gather_bufs.get(key)
+    if buf is None:
+        buf = _gather_bufs[key] = (torch.empty(2, bl, e, dtype=torch.float32, device=device),
+                                   torch.empty(world_size(), 2, bl, e, dtype=torch.float32, device=device))
+    return buf
+
+
 def all_gather_embeddings(img_local: torch.Tensor, txt_local: torch.Tensor):
-    """[Bl,E] x 2 -> [B,E] x 2 on every rank, rank-major (one collective on the fused [Bl, 2E] buffer)."""
-    if world_size() == 1:
+    """[Bl,E] x 2 -> [B,E] x 2 on every rank, rank-major: ONE collective on the fused [2, Bl, E] send buffer (received as
+    [world, 2, Bl, E]), then one strided copy per modality into the contiguous [B,E] the loss head reads."""
+    if not active():
+        if _sim["world"] > 1:
+            return _sim_gather(img_local, 0), _sim_gather(txt_local, 1)
         return img_local, txt_local
     bl, e = img_local.shape
-    fused = torch.cat([img_local, txt_local], dim=1).contiguous()
-    out = torch.empty(bl * world_size(), 2 * e, dtype=fused.dtype, device=fused.device)
-    if dist.get_backend() == "gloo" and fused.is_cuda:   # rehearsal path only: gloo has no CUDA all_gather_into_tensor
-        parts = [torch.empty_like(fused) for _ in range(world_size())]
-        dist.all_gather(parts, fused)
-        out = torch.cat(parts, dim=0)
+    w = world_size()
+    send, recv = gather_send_buffer(bl, e, img_local.device)
+    if img_local.data_ptr() != send[0].data_ptr():
+        send[0].copy_(img_local)
+    if txt_local.data_ptr() != send[1].data_ptr():
+        send[1].copy_(txt_local)
+    if dist.get_backend() == "gloo" and send.is_cuda:   # rehearsal path only: gloo has no CUDA all_gather_into_tensor
+        parts = [torch.empty_like(send) for _ in range(w)]
+        dist.all_gather(parts, send)
+        recv = torch.stack(parts, dim=0)
     else:
-        dist.all_gather_into_tensor(out, fused)
-    return out[:, :e].contiguous(), out[:, e:].contiguous()
+        dist.all_gather_into_tensor(recv.view(w * 2, bl, e), send)     # out = concatenation along dim 0
+    return recv[:, 0].reshape(w * bl, e), recv[:, 1].reshape(w * bl, e)   # reshape of a strided view = the one copy
 
 
 def local_rows(full: torch.Tensor):
     """This rank's rows of a gathered [B,E] tensor (the backward of the gather needs no collective)."""
-    if world_size() == 1:
-        return full
+    if not active():
+        return full[: full.shape[0] // _sim["world"]].contiguous() if _sim["world"] > 1 else full
     a, b = shard_bounds(full.shape[0], get_rank(), world_size())
     return full[a:b].contiguous()
 
 
 def broadcast_parameters(model):
-    if world_size() > 1:
+    if active():
         dist.broadcast(model.flat, src=0)
         model.refresh_shadows(full=True)
 
@@ -94,7 +144,7 @@ class GradSync:
         model.comm = self
 
     def bucket_ready(self, name: str):
-        if world_size() == 1:
+        if not active():
             return
         a, b = self.spans[name]
         self.pending.append(dist.all_reduce(self.model.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))

@@ -24,7 +24,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
-from ._lib import BlockDesc, ScError, SC_BF16, SC_F32, sc_dtype
+from ._lib import BlockDesc, EventSet, ScError, SC_BF16, SC_F32, sc_dtype
 
 CONFIGS = {
     "ViT-B-32": dict(embed_dim=512, image_size=224, patch=32, v_width=768, v_layers=12, v_heads=12,
@@ -63,6 +63,7 @@ class _Tower:
         self.batch = 0
         self.descs = []
         self.bufs = {}
+        self.events = None
 
 
 class ClipModel:
@@ -321,8 +322,12 @@ class ClipModel:
                 self._scratch[f"bwd.{tower.kind}.{key}"] = torch.empty(n, dtype=dt, device=dev)
         tower.batch = batch
         tower.descs = []
+        if self.dtype == torch.bfloat16 and tower.events is None:
+            tower.events = EventSet()    # the blocks of one tower are enqueued one after the other from this thread: one set per tower
         for i in range(tower.layers):
             d = BlockDesc()
+            if tower.events is not None:
+                tower.events.bind(d)
             d.batch, d.seq, d.width, d.heads, d.mlp_width = batch, tower.seq, w, tower.heads, mlp
             d.dtype, d.causal = sc_dtype(T), tower.causal
             p = f"{tower.prefix}{i}."

@@ -144,10 +144,10 @@ def sparsify_fwd_bwd(x, grad_scale=1.0, need_grad=True):
     return loss, dx
 
 
-def l2norm_fwd(x, eps=0.0):
+def l2norm_fwd(x, eps=0.0, out=None):
     require_gpu(x, "x", torch.float32)
     b, e = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else require_gpu(out, "out", torch.float32)
     inv = torch.empty(b, dtype=torch.float32, device=x.device)
     LIB.call("sc_l2norm_fwd", ptr(x), b, e, float(eps), ptr(y), ptr(inv), stream_ptr())
     return y, inv

@@ -95,8 +95,9 @@ class Trainer:
             txt_e = m.text_forward(tokens)                                         # :769
         img_e = m.image_forward(images)                                            # :768
         main.wait_stream(self.text_stream)
-        img_n, inv_i = ops.l2norm_fwd(img_e, 0.0)                                  # :772
-        txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0)                                  # :773
+        send = D.gather_send_buffer(img_e.shape[0], img_e.shape[1], img_e.device)[0] if D.active() else (None, None)
+        img_n, inv_i = ops.l2norm_fwd(img_e, 0.0, out=send[0])                     # :772 (written straight into the gather's send buffer)
+        txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0, out=send[1])                     # :773
         img_all, txt_all = D.all_gather_embeddings(img_n, txt_n)
         temp = float(self.temperature.detach()) if self.learnable_t else float(self.temperature)
         res = step_loss(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)   # :778-938
@@ -133,6 +134,15 @@ class Trainer:
         self.pending_logs = []
 
 
+def recall_from_ranks(rank: torch.Tensor, prefix: str) -> dict:
+    """R@1/5/10 and their mean as percentages rounded to 4 dp from the 0-based rank of each query's true match
+    (reference compute_metric_ret, sparsify_clip.py:382-392, :404-414, which finds the rank with a Python list.index loop)."""
+    n = rank.numel()
+    r = [(rank < k).sum().item() / n for k in (1, 5, 10)]
+    return {f"{prefix}_r1": round(r[0] * 100, 4), f"{prefix}_r5": round(r[1] * 100, 4), f"{prefix}_r10": round(r[2] * 100, 4),
+            f"{prefix}_ravg": round(sum(r) / 3 * 100, 4)}
+
+
 def evaluate_model(model, test_loader, device, plot_embeddings=False, logger=None, tokenizer=None):
     """Retrieval + geometry metrics with the reference's keys (:534-676).  Plots (UMAP/t-SNE/PCA, :599-620) are out of scope."""
     was_training = model.training
@@ -151,14 +161,7 @@ def evaluate_model(model, test_loader, device, plot_embeddings=False, logger=Non
     txt, _ = ops.l2norm_fwd(torch.cat(txts), 0.0)
     score = ops.gemm_f32(txt, img, trans_b=True)        # [N_text, N_image]  :628
     rank_f, rank_b, top_f, top_b = ops.retrieval_ranks(score)
-    n = score.shape[0]
-
-    def recall(rank, prefix):
-        r = [(rank < k).sum().item() / n for k in (1, 5, 10)]
-        return {f"{prefix}_r1": round(r[0] * 100, 4), f"{prefix}_r5": round(r[1] * 100, 4), f"{prefix}_r10": round(r[2] * 100, 4),
-                f"{prefix}_ravg": round(sum(r) / 3 * 100, 4)}
-
-    final_log = {**recall(rank_f, "forward"), **recall(rank_b, "backward"),
+    final_log = {**recall_from_ranks(rank_f, "forward"), **recall_from_ranks(rank_b, "backward"),
                  "gap": round(U.compute_gap(img, txt), 4),
                  "mean_angular_value_image": round(U.compute_mean_angular_value_of_a_modality(img), 4),
                  "mean_angular_value_text": round(U.compute_mean_angular_value_of_a_modality(txt), 4),

@@ -69,3 +69,62 @@ def test_dp2_step_equals_dp1_step():
         assert torch.allclose(proj, ref_model.param("visual.proj").cpu(), rtol=1e-4, atol=1e-6)
         assert torch.allclose(emb, ref_model.param("token_embedding.weight").cpu(), rtol=1e-4, atol=1e-6)
     assert out[0][0] == out[1][0]      # both ranks evaluate the identical global-batch loss
+
+
+def _run_rccl_world1(rank, port, out):
+    """One rank, backend nccl (= RCCL): every collective of the DP step really goes through RCCL on the one GPU of the box."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("SC_DIST_BACKEND", None)
+    import torch.distributed as tdist
+    from sparsify_clip_amd import dist as D
+    from sparsify_clip_amd.model import ClipModel
+    from sparsify_clip_amd.train import Trainer
+    torch.cuda.set_device(0)
+    res = {}
+    for precision in ("fp32", "bf16"):       # bf16: the gradient buckets are handed over from two towers' streams + side streams
+        cfg = dict(_cfg(), precision=precision)
+        runs = []
+        for grouped in (False, True):
+            if grouped and not tdist.is_initialized():
+                D.init_process_group(backend="nccl", force=True)
+                assert D.active() and D.world_size() == 1 and tdist.get_backend() == "nccl"
+            model = ClipModel("tiny", device="cuda:0", precision=precision, seed=7)
+            tr = Trainer(cfg, "cuda:0", 4, model=model)
+            losses = [tr.step(i.cuda(), t.cuda()).item() for i, t in _batches(3)]
+            torch.cuda.synchronize()
+            runs.append((losses, model.flat.clone()))
+        res[precision] = (runs[0][0] == runs[1][0], bool(torch.equal(runs[0][1], runs[1][1])), runs[1][0])
+    # the pieces on their own
+    img, txt = torch.randn(8, 64, device="cuda:0"), torch.randn(8, 64, device="cuda:0")
+    gi, gt = D.all_gather_embeddings(img, txt)
+    res["gather"] = bool(torch.equal(gi, img) and torch.equal(gt, txt) and torch.equal(D.local_rows(gi), img))
+    model = ClipModel("tiny", device="cuda:0", precision="fp32", seed=3)
+    before = model.flat.clone()
+    D.broadcast_parameters(model)
+    sync = D.GradSync(model)
+    model.flat_grad.normal_()
+    g0 = model.flat_grad.clone()
+    for name, _ in model.buckets:
+        sync.bucket_ready(name)
+    res["pending"] = len(sync.pending)
+    sync.wait_all()
+    torch.cuda.synchronize()
+    res["allreduce"] = bool(torch.equal(model.flat_grad, g0) and torch.equal(model.flat, before))
+    out.update(res)
+    tdist.destroy_process_group()
+
+
+def test_rccl_world1_collectives_and_step():
+    """RCCL itself (backend "nccl") on the one GPU of the box: a world-size-1 process group makes all_gather_into_tensor, the
+    bucketed async SUM all-reduces (issued from the towers' streams) and the parameter broadcast real RCCL calls; at world 1 they
+    are identities, so the grouped trainer must reproduce the un-grouped one BIT for bit, in fp32 and in bf16 (4 streams)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_run_rccl_world1, args=(_free_port(), out), nprocs=1, join=True)
+    out = dict(out)
+    assert out["gather"] and out["allreduce"] and out["pending"] == 8, out        # 2 towers x (head + 2 blocks + stem) buckets of the tiny model
+    for precision in ("fp32", "bf16"):
+        same_loss, same_params, losses = out[precision]
+        assert same_loss and same_params, (precision, out)

@@ -320,7 +320,9 @@ def test_full_size_step_properties_bf16(pkg):
     """BASELINE size (ViT-B/32, local batch 1024, bf16, experiment-6 loss stack, four concurrent streams): size-independent
     properties instead of an oracle the CPU could not finish - (1) two trainers from the same seed produce BIT-IDENTICAL losses
     and parameters over 3 steps (no atomics, fixed-order reductions, event-ordered streams); (2) the loss of the first step
-    equals the loss head evaluated alone on the step's embeddings; (3) parameters stay finite and move."""
+    EQUALS (bit for bit) the loss head evaluated alone on the embeddings of the same pre-update weights; (3) parameters stay
+    finite and move.  The numeric distance of this bf16 path to the fp32 parity path at real size is bounded in
+    test_bf16_path_distance_to_fp32_path_real_size."""
     from conftest import load_json
     from sparsify_clip_amd import ops
     from sparsify_clip_amd.config import finalize_config
@@ -335,22 +337,56 @@ def test_full_size_step_properties_bf16(pkg):
     for _ in range(2):
         tr = Trainer(cfg, DEV, 1000)
         tr.epoch = 1
+        if not runs:   # (2): the loss head alone on the embeddings of the SAME, pre-update weights (same kernels, so bit-equal)
+            m = tr.model
+            ie, _ = ops.l2norm_fwd(m.image_forward(images), 0.0)
+            te, _ = ops.l2norm_fwd(m.text_forward(tokens), 0.0)
+            alone = step_loss(cfg, ie, te, 0.1, 1, 1, tr.t_total).loss.item()
         losses = [tr.step(images, tokens).item() for _ in range(3)]
         torch.cuda.synchronize()
         runs.append((losses, tr.model.flat.clone()))
-        if len(runs) == 1:
-            m = tr.model
-            with torch.no_grad():
-                ie, _ = ops.l2norm_fwd(m.image_forward(images), 0.0)
-                te, _ = ops.l2norm_fwd(m.text_forward(tokens), 0.0)
-            alone = step_loss(cfg, ie, te, 0.1, 1, 4, tr.t_total).loss.item()
-            assert np.isfinite(alone)
         del tr
         torch.cuda.empty_cache()
+    assert alone == runs[0][0][0], (alone, runs[0][0][0])
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1])
     assert all(np.isfinite(l) for l in runs[0][0]) and torch.isfinite(runs[0][1]).all()
     assert runs[0][0][0] != runs[0][0][2]          # the optimiser moved the model (step 1 runs at lr 0)
+
+
+def test_bf16_path_distance_to_fp32_path_real_size(pkg):
+    """The benchmarked bf16 path against the 1e-4-parity fp32 path ON THE GPU at real size (ViT-B/32, batch 256, experiment-6 stack,
+    identical weights and batch): the step loss differs by <= 2e-2 relative (the documented bf16 bound; measured ~1e-3), the
+    normalised embeddings by <= 3e-2 relative, and after 3 optimiser steps the two trajectories still agree to 2e-2."""
+    from conftest import load_json
+    from sparsify_clip_amd import ops
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.data import synthetic_batch
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if "experiment_6-" in k][0]]
+    images, tokens = [t.to(DEV) for t in synthetic_batch(43, 256)]
+    out = {}
+    sd = None
+    for precision in ("fp32", "bf16"):
+        cfg = finalize_config(raw, 0, {"model": "ViT-B-32", "batch_size": 256, "precision": precision})
+        tr = Trainer(cfg, DEV, 1000)
+        if sd is None:
+            sd = tr.model.state_dict()
+        else:
+            tr.model.load_state_dict(sd)
+        tr.epoch = 1
+        ie, _ = ops.l2norm_fwd(tr.model.image_forward(images), 0.0)
+        te, _ = ops.l2norm_fwd(tr.model.text_forward(tokens), 0.0)
+        losses = [tr.step(images, tokens).item() for _ in range(4)]     # the optimiser moves the weights between the steps
+        out[precision] = (losses, ie.clone(), te.clone())
+        del tr
+        torch.cuda.empty_cache()
+    l32, l16 = out["fp32"][0], out["bf16"][0]
+    gaps = [abs(a - b) / abs(a) for a, b in zip(l32, l16)]
+    print("bf16 vs fp32 step-loss gaps:", gaps, "embedding rel errs:", rel_err(out["bf16"][1], out["fp32"][1]), rel_err(out["bf16"][2], out["fp32"][2]))
+    assert max(gaps) <= 2e-2, (l32, l16)
+    assert rel_err(out["bf16"][1], out["fp32"][1]) <= 3e-2 and rel_err(out["bf16"][2], out["fp32"][2]) <= 3e-2
 
 
 def test_c5_vit_l14_step_runs_bf16(pkg):

@@ -1,0 +1,144 @@
+"""GPU parity tests, host-surface level: the reference-generated fixtures that round 1 only replayed against the CPU oracle are
+replayed here against the HIP path itself -
+
+  * tests/golden/dispatch.json (the reference's own if/elif at sparsify_clip.py:778-938, executed from its AST on stored
+    32x512 inputs: 13 YAMLs x 5 (epoch, current_batch) rows) through loss_dispatch.step_loss - all nine loss_type strings;
+  * tests/golden/metrics.json (uniformity.py:6-205, sparsify_clip.py:357-528) through the five uniformity functions, gap /
+    angular / true-pair metrics and evaluate_model's rank -> recall arithmetic on CUDA tensors;
+  * the experiment runner (sparsify_clip.run: epoch loop, phase switch by epoch, periodic + final checkpoints, JSONL keys,
+    reference :943-951, :659-667, :983, :1118) end to end on the tiny model.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device(DEV)
+
+
+def test_dispatch_fixture_through_step_loss(gpu, golden_small):
+    """Every row of dispatch.json: loss within 1e-4 relative, gradient norms within 1e-3, beta / alpha exact."""
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.loss_dispatch import LOSS_TABLE, step_loss
+    arr, _ = golden_small
+    img = torch.tensor(arr["rand32x512/img"]).to(gpu)
+    txt = torch.tensor(arr["rand32x512/txt"]).to(gpu)
+    cfgs, disp = load_json("configs.json"), load_json("dispatch.json")
+    assert len(disp) == 13
+    seen = set()
+    for rel, entry in disp.items():
+        cfg = finalize_config(cfgs[rel], 0, {"model": "ViT-B-32"})
+        assert cfg["loss_type"] == entry["loss_type"]
+        seen.add(cfg["loss_type"])
+        for row in entry["rows"]:
+            res = step_loss(cfg, img, txt, cfg["anchor_temperature"], row["epoch"], row["current_batch"], row["t_total"])
+            got = res.loss.item()
+            assert abs(got - row["loss"]) <= 1e-4 * abs(row["loss"]), (rel, row, got)
+            for g, key in ((res.d_img, "dimg_norm"), (res.d_txt, "dtxt_norm")):
+                n = g.double().norm().item()
+                assert abs(n - row[key]) <= 1e-3 * row[key], (rel, row, key, n)
+            assert (0.0 if res.beta is None else res.beta) == row["beta"], (rel, row, res.beta)
+            assert (0.0 if res.alpha is None else res.alpha) == row["alpha"], (rel, row, res.alpha)
+    assert seen == set(LOSS_TABLE) and len(seen) == 9          # incl. the :782, :909 and :922 strings
+    k7, k8 = [k for k in disp if "experiment_7" in k][0], [k for k in disp if "experiment_8" in k][0]
+    assert disp[k7]["loss_type"] == disp[k8]["loss_type"]       # exp-8's string runs exp-7's arithmetic (first match wins)
+
+
+def test_uniformity_and_geometry_metrics_on_device(gpu, golden_metrics):
+    """The device covariance / Gram path (sc_gemm_f32) of uniformity.py's five functions and the eval geometry metrics against
+    the reference's own values; same tolerances as the CPU-tensor test in tests/test_host_logic.py."""
+    import uniformity as U                              # root alias module, as the reference imports it (:27)
+    from sparsify_clip_amd import uniformity as PU
+    arr, v = golden_metrics
+    f1, f2 = torch.tensor(arr["f1"]).to(gpu), torch.tensor(arr["f2"]).to(gpu)
+    got = U.numpy_uniformity(f1, f2)
+    assert isinstance(got, float) and abs(got - v["numpy_uniformity"]) < 1e-5
+    assert abs(U.torch_uniformity(f1, f2).item() - v["torch_uniformity"]) < 1e-5
+    assert abs(U.torch_uniformity1(f1).item() - v["torch_uniformity1"]) < 1e-5
+    assert abs(U.torch_uniformity_equivalent(f1).item() - v["torch_uniformity_equivalent"]) < 1e-5
+    assert abs(U.uniformity10(f1).item() - v["uniformity10"]) < 1e-4
+    assert abs(PU.uniformity(f1, f2) - v["sparsify_clip.uniformity"]) < 1e-5
+    assert abs(PU.compute_gap(f1, f2) - v["compute_gap"]) < 1e-6
+    assert abs(PU.compute_mean_angular_value_of_a_modality(f1) - v["mean_angular_value_f1"]) < 1e-6
+    assert abs(PU.mean_distance_of_true_pairs(f1, f2) - v["mean_distance_of_true_pairs"]) < 1e-6
+
+
+def test_recall_dicts_from_device_ranks(gpu, golden_metrics):
+    """evaluate_model's rank -> R@1/5/10/avg arithmetic (train.recall_from_ranks) on the device ranks == the reference's
+    compute_metric_ret dictionaries (sparsify_clip.py:357-416), exactly."""
+    from sparsify_clip_amd import ops
+    from sparsify_clip_amd.train import recall_from_ranks
+    arr, v = golden_metrics
+    f1, f2 = torch.tensor(arr["f1"]), torch.tensor(arr["f2"])
+    score = (f2 @ (0.6 * f2 + 0.4 * f1).t()).to(gpu)
+    rank_f, rank_b, _, _ = ops.retrieval_ranks(score)
+    assert recall_from_ranks(rank_f, "forward") == v["retrieval_forward"]
+    assert recall_from_ranks(rank_b, "backward") == v["retrieval_backward"]
+    # the fixture's score is nearly diagonal (all recalls 100 %): a hard case with spread-out ranks against the oracle's dictionaries
+    from oracle import metrics as M
+    hard = f2 @ (0.05 * f2 + 0.95 * f1).t()
+    rank_f, rank_b, _, _ = ops.retrieval_ranks(hard.to(gpu))
+    want_f, want_b = M.retrieval_metrics(hard, "forward"), M.retrieval_metrics(hard, "backward")
+    assert 0.0 < want_f["forward_r1"] < 100.0
+    assert recall_from_ranks(rank_f, "forward") == want_f and recall_from_ranks(rank_b, "backward") == want_b
+
+
+def test_runner_end_to_end(gpu, tmp_path, monkeypatch):
+    """sparsify_clip.run([...]) on a temp YAML: 2 epochs x 3 steps of the tiny model, only_lunif_epochs = 1 -> the first epoch runs
+    the warm-up branch (lunif terms only), the second the full stack; both per-epoch checkpoints and the final one exist with
+    `module.`-prefixed open_clip keys; the JSONL carries the reference's key sets."""
+    import yaml
+    import sparsify_clip
+    from sparsify_clip_amd import train as T
+    cfg = {"project_name": "t", "run_name": "runner_test", "seed": 42, "learning_rate": "1e-3", "batch_size": 8, "model": "RN50",
+           "num_train_samples": 64, "num_test_samples": 16, "epochs": 2,
+           "loss_type": "only_lunif_n_then_anchor+lalign+lunif(centroids)", "only_lunif_epochs": 1, "anchor_temperature": 0.1,
+           "anchor_temperature_learnable": False, "save_checkpoint_every_n_epochs": 1, "resume_checkpoint": False, "fp16": False}
+    path = tmp_path / "exp.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    monkeypatch.chdir(tmp_path)
+    calls = []
+    real = T.step_loss
+
+    def spy(config, img, txt, temp, epoch, current_batch, t_total, **kw):
+        res = real(config, img, txt, temp, epoch, current_batch, t_total, **kw)
+        calls.append((epoch, current_batch, sorted(res.terms)))
+        return res
+
+    monkeypatch.setattr(T, "step_loss", spy)
+    from sparsify_clip_amd._lib import ScError
+    with pytest.raises(ScError, match="--model"):
+        sparsify_clip.run(["--config", str(path), "--device", "0"])                 # the YAML's literal RN50
+    out = sparsify_clip.run(["--config", str(path), "--device", "0", "--model", "tiny", "--steps-per-epoch", "3", "--precision", "fp32"])
+    assert set(out) == {"runner_test"} and np.isfinite(out["runner_test"]["final"]["gap"])
+    assert [c[0] for c in calls] == [0, 0, 0, 1, 1, 1] and [c[1] for c in calls] == [1, 2, 3, 4, 5, 6]
+    assert all(c[2] == ["lunif_img", "lunif_txt"] for c in calls[:3])                 # :795-799 warm-up phase
+    assert all(c[2] == ["anchor", "lalign", "lunif_centroids"] for c in calls[3:])    # :800-809 main phase
+    for name in ("runner_test_epoch_1.pt", "runner_test_epoch_2.pt", "runner_test.pt"):
+        sd = torch.load(tmp_path / "models" / name, map_location="cpu", weights_only=True)
+        assert all(k.startswith("module.") for k in sd) and "module.visual.conv1.weight" in sd and "module.logit_scale" in sd
+    rows = [json.loads(line) for line in open(tmp_path / "logs" / "runner_test.jsonl")]
+    train_rows = [r for r in rows if "train_loss" in r]
+    eval_rows = [r for r in rows if "forward_r1" in r]
+    assert len(train_rows) == 6 and all(set(r) == {"train_loss", "learning_rate", "beta", "alpha"} for r in train_rows)
+    eval_keys = {f"{d}_{k}" for d in ("forward", "backward") for k in ("r1", "r5", "r10", "ravg")} | {
+        "gap", "mean_angular_value_image", "mean_angular_value_text", "uniformity", "mean_cosine_similarity_true_pairs"}
+    assert len(eval_rows) == 4 and all(set(r) == eval_keys for r in eval_rows)       # :740, :980 x 2, :1115
+    # resume (:719-724): weights only, `module.` keys accepted
+    from sparsify_clip_amd.model import ClipModel
+    m = ClipModel("tiny", device=DEV, precision="fp32", seed=99)
+    m.load_state_dict(torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True))
+    sd = torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True)
+    assert torch.equal(m.param("visual.proj").cpu(), sd["module.visual.proj"])

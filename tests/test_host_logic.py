@@ -38,9 +38,12 @@ def test_dispatch_table_covers_every_reference_yaml():
     for rel, raw in cfgs.items():
         if raw is None:
             continue
-        cfg = finalize_config(raw, 3)
+        assert raw["model"] == "RN50"
+        with pytest.raises(ScError, match="--model ViT-B-32"):     # RN50 is rejected at load time, naming the override
+            finalize_config(raw, 3)
+        cfg = finalize_config(raw, 3, {"model": "ViT-B-32"})
         assert cfg["device_id"] == 3 and isinstance(cfg["learning_rate"], float) and cfg["learning_rate"] == 1e-4
-        assert cfg["precision"] == "bf16" and cfg["model"] == "RN50" and cfg["batch_size"] == 256
+        assert cfg["precision"] == "bf16" and cfg["model"] == "ViT-B-32" and cfg["batch_size"] == 256
         seen.add(cfg["loss_type"])
     assert seen == set(LOSS_TABLE) and len(seen) == 9
     for name, warm, unif, use_beta, use_alpha, use_lalign in TABLE:      # package table == oracle table (pinned by dispatch.json)

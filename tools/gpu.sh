@@ -1,0 +1,71 @@
+#!/bin/bash
+# The one GPU-box driver script (run through gpurun from the repo root):   bash tools/gpu.sh <task> [<task> ...]
+# Tasks run in the order given and stop at the first failing one.  Everything logs under gpurun_out/ (merged back by gpurun);
+# what should be judged is copied from there into profiles/ by hand.  rocprofv3 always gets the python program directly after `--`.
+#   tests        python -m pytest tests -m gpu            -> gpurun_out/pytest_gpu.log            (PYTEST_ARGS to narrow)
+#   bench        python bench.py                          -> gpurun_out/bench.json / bench.err    (BENCH_ARGS, STEPS)
+#   prof         rocprofv3 --kernel-trace --stats of bench.py (3 steps)          -> gpurun_out/prof/bench_kernel_stats.csv
+#   replay       rocprofv3 --kernel-trace --stats of tools/gemm_replay.py (ONE stream: bench.py's roofline launch set)
+#                                                         -> gpurun_out/replay/replay_kernel_stats.csv + per-shape table
+#   gemm         tools/gemm_bench.py per-shape TF/s       -> gpurun_out/gemm_shapes.txt
+#   pmc_gemm     SQ counter passes (MFMA busy ...) on the NT / TN kernels, three shapes each -> gpurun_out/pmc/gemm_counters.txt
+#   pmc_traffic  FETCH_SIZE / WRITE_SIZE passes over the replay launch set   -> gpurun_out/gemm_traffic.json
+#   pmc_loss     FETCH_SIZE / WRITE_SIZE + kernel times of the loss head at B = 8192 -> gpurun_out/pmc/loss_counters.txt
+#   loss         tools/loss_bench.py                       -> gpurun_out/loss_head_times.txt
+#   dp2          python bench.py --gpus 2 under SC_DIST_BACKEND=gloo on the one GPU (self-launch rehearsal) -> gpurun_out/dp2.json
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out/prof $R/gpurun_out/pmc $R/gpurun_out/replay
+export TMPDIR=/tmp
+PMC() { # name, counters..., -- program args
+  name=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  (cd /tmp && timeout -k 10 ${PMC_TIMEOUT:-400} rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$name -o p -- python3 "$@" > $R/gpurun_out/pmc/$name.log 2>&1)
+  rc=$?; echo "pmc $name rc=$rc"; return $rc
+}
+for task in "$@"; do
+  cd $R
+  case $task in
+    tests)
+      timeout -k 10 ${TEST_TIMEOUT:-1100} python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1; rc=$?
+      echo "pytest rc=$rc"; tail -5 gpurun_out/pytest_gpu.log; grep -E "^FAILED|^ERROR" gpurun_out/pytest_gpu.log | head -20
+      [ $rc = 0 ] || exit $rc ;;
+    bench)
+      timeout -k 10 600 python bench.py --steps ${STEPS:-8} --warmup 2 ${BENCH_ARGS} > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
+      echo "bench rc=$rc"; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json
+      [ $rc = 0 ] || exit $rc ;;
+    dp2)
+      SC_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --warmup 1 --local-batch ${DP2_BATCH:-256} > gpurun_out/dp2.json 2> gpurun_out/dp2.err; rc=$?
+      echo "dp2 rc=$rc"; tail -3 gpurun_out/dp2.err; cat gpurun_out/dp2.json
+      [ $rc = 0 ] || exit $rc ;;
+    prof)
+      (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --simulate-dp 1 ${BENCH_ARGS} > $R/gpurun_out/rocprof.log 2>&1); rc=$?
+      echo "rocprof rc=$rc"
+      find $R/gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+      python3 tools/kernel_stats.py $R/gpurun_out/prof/bench_kernel_stats.csv 24
+      [ $rc = 0 ] || exit $rc ;;
+    replay)
+      (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/replay -o replay -- python3 $R/tools/gemm_replay.py > $R/gpurun_out/replay.log 2>&1); rc=$?
+      echo "replay rc=$rc"
+      python3 tools/kernel_stats.py $R/gpurun_out/replay/replay_kernel_stats.csv 10
+      python3 tools/replay_table.py $R/gpurun_out/replay/replay_kernel_trace.csv > $R/gpurun_out/replay/replay_per_launch.txt; cat $R/gpurun_out/replay/replay_per_launch.txt
+      find $R/gpurun_out/replay -name "*kernel_trace.csv" -size +20M -delete
+      [ $rc = 0 ] || exit $rc ;;
+    gemm)
+      timeout -k 10 600 python tools/gemm_bench.py > gpurun_out/gemm_shapes.txt 2>&1; rc=$?; cat gpurun_out/gemm_shapes.txt; [ $rc = 0 ] || exit $rc ;;
+    loss)
+      timeout -k 10 600 python tools/loss_bench.py > gpurun_out/loss_head_times.txt 2>&1; rc=$?; cat gpurun_out/loss_head_times.txt; [ $rc = 0 ] || exit $rc ;;
+    pmc_gemm)
+      PMC g_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -- $R/tools/gemm_one.py || exit 1
+      PMC g_sq2 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -- $R/tools/gemm_one.py || exit 1
+      python3 tools/pmc_table.py gemm_bf16 $R/gpurun_out/pmc/g_sq1 $R/gpurun_out/pmc/g_sq2 > $R/gpurun_out/pmc/gemm_counters.txt; cat $R/gpurun_out/pmc/gemm_counters.txt ;;
+    pmc_traffic)
+      PMC t_fetch FETCH_SIZE -- $R/tools/gemm_replay.py || exit 1
+      PMC t_write WRITE_SIZE -- $R/tools/gemm_replay.py || exit 1
+      python3 tools/pmc_traffic.py $R/gpurun_out/pmc/t_fetch $R/gpurun_out/pmc/t_write > $R/gpurun_out/gemm_traffic.json; cat $R/gpurun_out/gemm_traffic.json ;;
+    pmc_loss)
+      PMC l_fetch FETCH_SIZE -- $R/tools/loss_one.py || exit 1
+      PMC l_write WRITE_SIZE GRBM_GUI_ACTIVE -- $R/tools/loss_one.py || exit 1
+      python3 tools/pmc_table.py "" $R/gpurun_out/pmc/l_fetch $R/gpurun_out/pmc/l_write > $R/gpurun_out/pmc/loss_counters.txt; cat $R/gpurun_out/pmc/loss_counters.txt ;;
+    *) echo "unknown task $task"; exit 2 ;;
+  esac
+  find $R/gpurun_out/pmc -name "*.csv" -size +8M -delete 2>/dev/null
+done
