@@ -230,6 +230,9 @@ __global__ __launch_bounds__(256) void attn_ds_rows_f32_kernel(const float* p, f
 }
 }  // namespace
 
+// fp32 backward kernel: q, k, v, dO tiles + scores + dP of one head in LDS
+bool sc_attention_f32_bwd_fits_lds(int64_t seq) { return ((size_t)4 * seq * HDP + 2 * seq * (seq + 1)) * sizeof(float) <= 160 * 1024; }
+
 int sc_attention_f32_composed_fwd(const float* qkv, float* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, void* ws,
                                   size_t ws_bytes, hipStream_t st) {
     SC_REQUIRE(qkv && out && ws, SC_ERR_ARG, "attention (fp32, long): null argument");

@@ -22,6 +22,8 @@ int sc_attention_f32_composed_fwd(const float* qkv, float* out, int64_t batch, i
 int sc_attention_f32_composed_bwd(const float* qkv, const float* d_out, float* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                                   void* ws, size_t ws_bytes, hipStream_t st);
 
+bool sc_attention_f32_bwd_fits_lds(int64_t seq);
+
 int sc_gelu_fwd_bf16(const void* pre, void* act, int64_t n_elems, hipStream_t st);
 int sc_dgelu_mul_colsum_bf16(void* dh, const void* pre, int64_t rows, int64_t n, float* colsum, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -214,7 +216,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
         SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
     }
     // in_proj's bias gradient = column sums of d_qkv: taken by the attention backward while dq / dk / dv are in registers
-    if (dt == SC_F32 && d->seq > 128)
+    if (dt == SC_F32 && !sc_attention_f32_bwd_fits_lds(d->seq))   // the one-workgroup-per-head fp32 backward holds S x S scores and dP in LDS
         SC_TRY(sc_attention_f32_composed_bwd((const float*)d->qkv, (const float*)d->d_attn, (float*)d->d_qkv, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, st));
     else if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
     else SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));

@@ -617,6 +617,285 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
     }
 }
 
+// LDS-DMA with a uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset, written out so that the compiler cannot widen
+// the eight offsets back into eight 64-bit pointers (16 VGPRs the AGPR kernels do not have).  M0 = LDS destination of the wave.
+__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");   // M0 is written; the kernels using it have no compiler-generated M0 user
+}
+
+// ------------------------------------------------------------------------------------------------ NT, 256x256, persistent
+// The kernel above pays, per 256x256 tile at K = 768, ~12 us of prologue + epilogue with idle MFMA units against ~18 us of main
+// loop (workgroup launch, first LDS-DMA round trip, epilogue through slabs that alias the operand stages, teardown).  This
+// kernel keeps its main loop (same wave tile, same AGPR accumulators, same hand-placed MFMA / ds_read order) and removes what
+// sits between two tiles, for the problems the training step is made of - whole 256x256 tiles and one of four epilogues:
+//   * ONE workgroup per CU walks a list of tiles (virtual block ids blockIdx.x + r * gridDim.x through the same XCD-aware
+//     band/cell remap, so every tile still runs on the XCD the one-tile-per-workgroup kernel would give it);
+//   * the epilogue slabs do not alias the operand stages: LDS = 2 stages (128 KiB) + eight 4-KiB per-wave slabs = 160 KiB.
+//     A slab holds ONE 16-row MFMA row tile (16 x 64 fp32, 16-byte pieces XOR-swizzled by the row instead of padded), so the
+//     accumulators cross over to the row-major ownership in eight small passes per wave;
+//   * hence both stages are free as soon as the last K-tile's fragments are in registers: between the two sub-steps of the
+//     last K-tile (one extra barrier) the wave requests K-tiles 0 and 1 of its NEXT tile, which land under the last 32 MFMAs
+//     and the whole epilogue - the next main loop starts on resident data;
+//   * the epilogue's global operands (GELU' pre-activation, fp32 residual) are requested one row tile ahead;
+//   * with whole tiles nothing is clamped: LDS-DMA sources are a per-tile SGPR base + eight per-lane 32-bit offsets computed
+//     once per kernel, epilogue addresses a per-tile SGPR base + one per-lane offset.
+// The epilogue kind is a template parameter (each instance keeps only its own operands alive).  Everything else - ragged
+// shapes, alpha / beta, other epilogue combinations - stays on the one-tile-per-workgroup kernel above.
+constexpr int P_SLAB = 4096, P_LDS = 2 * B_STAGE + 8 * P_SLAB;   // 163840 B = all of the CU's LDS
+enum { NTP_BIAS = 0, NTP_GELU_PRE = 1, NTP_DGELU = 2, NTP_RESID = 3 };
+
+template <int EPI>
+struct NtpAux {   // epilogue operands of one 16-row tile: two groups of 8 rows, 8 columns per lane
+    uint4 hpre[EPI == NTP_DGELU ? 2 : 1];
+    f32x4 r0[EPI == NTP_RESID ? 2 : 1], r1[EPI == NTP_RESID ? 2 : 1];
+};
+
+struct NtpEpi {   // per-tile epilogue context: uniform bases (SGPRs) + this lane's offsets
+    char* c;                // C tile origin of this wave's 128x64 sub-tile
+    const char* aux;        // dgelu_pre (bf16) or resid (fp32), same origin
+    char* pre;              // pre_out (bf16), same origin
+    unsigned row_bytes_c, row_bytes_aux, row_bytes_pre;   // bytes per matrix row
+    unsigned voff_c, voff_aux, voff_pre;                  // lane: (erow * ld + ecol) * element size
+    char* slab_wr;          // slab + frow * 256
+    const char* slab;       // wave's slab
+    f32x4 bias0, bias1;
+};
+
+__device__ __forceinline__ uint4 pack8_bf16(const f32x4& v0, const f32x4& v1) {
+    uint4 u;
+    u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
+    u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
+    u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
+    u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+    return u;
+}
+
+template <int EPI, int I>
+__device__ __forceinline__ void ntp_aux_load(NtpAux<EPI>& x, const NtpEpi& c) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const char* row = c.aux + (size_t)(16 * I + 8 * g) * c.row_bytes_aux;   // uniform
+        if constexpr (EPI == NTP_DGELU) x.hpre[g] = *(const uint4*)(row + c.voff_aux);
+        if constexpr (EPI == NTP_RESID) {
+            x.r0[g] = *(const f32x4*)(row + c.voff_aux);
+            x.r1[g] = *(const f32x4*)(row + c.voff_aux + 16);
+        }
+    }
+}
+
+// row tile I of the wave's 128x64 sub-tile: accumulators -> slab (MFMA ownership: row lane & 15, columns 16 j + 4 (lane >> 4) ..),
+// slab -> registers (row-major ownership: row lane >> 3 (+8), 8 columns 8 (lane & 7) ..), epilogue arithmetic, 16-byte stores.
+template <int EPI, int I>
+__device__ __forceinline__ void ntp_row_tile(const NtpEpi& c, int lane, const NtpAux<EPI>& x, bool do_cs, f32x4& cs0, f32x4& cs1) {
+    const int frow = lane & 15, fq = lane >> 4, erow = lane >> 3, ep = lane & 7;
+    *(f32x4*)(c.slab_wr + (((0 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 0>();
+    *(f32x4*)(c.slab_wr + (((4 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 1>();
+    *(f32x4*)(c.slab_wr + (((8 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 2>();
+    *(f32x4*)(c.slab_wr + (((12 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 3>();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int row = 8 * g + erow;
+        const char* rd = c.slab + row * 256;
+        f32x4 v0 = *(const f32x4*)(rd + (((2 * ep) ^ row) << 4)) + c.bias0;
+        f32x4 v1 = *(const f32x4*)(rd + (((2 * ep + 1) ^ row) << 4)) + c.bias1;
+        const size_t rsel = (size_t)(16 * I + 8 * g);
+        if constexpr (EPI == NTP_GELU_PRE) {
+            *(uint4*)(c.pre + rsel * c.row_bytes_pre + c.voff_pre) = pack8_bf16(v0, v1);
+            v0 = gelu_fast4(v0); v1 = gelu_fast4(v1);
+        }
+        if constexpr (EPI == NTP_DGELU) {
+            const uint4 hh = x.hpre[g];
+            v0 = gelu_grad_mul4(v0, hh.x, hh.y); v1 = gelu_grad_mul4(v1, hh.z, hh.w);
+        }
+        if constexpr (EPI == NTP_RESID) {
+            v0 += x.r0[g]; v1 += x.r1[g];
+            char* cp = c.c + rsel * c.row_bytes_c + c.voff_c;
+            *(f32x4*)cp = v0;
+            *(f32x4*)(cp + 16) = v1;
+        } else {
+            const uint4 u = pack8_bf16(v0, v1);
+            *(uint4*)(c.c + rsel * c.row_bytes_c + c.voff_c) = u;
+            if constexpr (EPI == NTP_DGELU) {
+                if (do_cs) {   // the values as stored (bf16-rounded): identical to a pass over C
+                    cs0[0] += __uint_as_float(u.x << 16); cs0[1] += __uint_as_float(u.x & 0xffff0000u);
+                    cs0[2] += __uint_as_float(u.y << 16); cs0[3] += __uint_as_float(u.y & 0xffff0000u);
+                    cs1[0] += __uint_as_float(u.z << 16); cs1[1] += __uint_as_float(u.z & 0xffff0000u);
+                    cs1[2] += __uint_as_float(u.w << 16); cs1[3] += __uint_as_float(u.w & 0xffff0000u);
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int I>
+__device__ __forceinline__ void ntp_epilogue_rows(const NtpEpi& c, int lane, const NtpAux<EPI>& cur, bool do_cs, f32x4& cs0, f32x4& cs1) {
+    NtpAux<EPI> nxt;
+    if constexpr (I + 1 < 8 && (EPI == NTP_DGELU || EPI == NTP_RESID)) ntp_aux_load<EPI, I + 1>(nxt, c);
+    ntp_row_tile<EPI, I>(c, lane, cur, do_cs, cs0, cs1);
+    if constexpr (I + 1 < 8) ntp_epilogue_rows<EPI, I + 1>(c, lane, nxt, do_cs, cs0, cs1);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(1024))) char smem[P_LDS];
+    constexpr bool OUT_F32 = EPI == NTP_RESID;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int GM = p.group_m, GN = p.group_n;
+    const int nk = p.K / KSTEP;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+
+    asm volatile("" ::: SC_ACC_AGPRS);   // reserves a0..a127 in the kernel descriptor
+
+    // LDS-DMA: per-lane byte offsets against a per-tile uniform base (tiles are whole: no row is clamped)
+    unsigned oa[4], ob[4];
+    {
+        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            oa[q] = (unsigned)(((wave * 32 + q * 8 + srow) * p.lda + schunk * 8) * 2);
+            ob[q] = (unsigned)(((wave * 32 + q * 8 + srow) * p.ldb + schunk * 8) * 2);
+        }
+    }
+    const char* a_tile;
+    const char* b_tile;
+    // virtual block id -> tile origin (the band / cell walk of the one-tile-per-workgroup kernel)
+#define NTP_TILE(VB, M0, N0)                                                                          \
+    do {                                                                                              \
+        const int tile__ = xcd_remap((VB), ntiles);                                                   \
+        const int band__ = tile__ / (GM * p.tiles_n), rb__ = tile__ - band__ * (GM * p.tiles_n);      \
+        const int rows__ = min(GM, p.tiles_m - band__ * GM);                                          \
+        const int cell__ = rb__ / (rows__ * GN), rc__ = rb__ - cell__ * (rows__ * GN);                \
+        const int gw__ = min(GN, p.tiles_n - cell__ * GN);                                            \
+        (M0) = (band__ * GM + rc__ / gw__) * B_M; (N0) = (cell__ * GN + rc__ % gw__) * B_N;           \
+        a_tile = (const char*)p.A + (int64_t)(M0) * p.lda * 2;                                        \
+        b_tile = (const char*)p.B + (int64_t)(N0) * p.ldb * 2;                                        \
+    } while (0)
+#define NTP_STAGE(S, KT)                                                                              \
+    do {                                                                                              \
+        const unsigned la__ = lds0 + (S) * B_STAGE + (wave * 32) * 128;                               \
+        const char* ak__ = a_tile + (KT) * (KSTEP * 2);                                               \
+        const char* bk__ = b_tile + (KT) * (KSTEP * 2);                                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16_saddr(ak__, oa[q], la__ + q * 1024);     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16_saddr(bk__, ob[q], la__ + B_A + q * 1024); \
+    } while (0)
+#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0)   /* tile KT is not the last one: as NTB_FULL */      \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        ntb_substep<0, true>(a, b0, b1, A_S1, B_S1);                                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) NTP_STAGE(S, (KT) + 2);                                                    \
+        ntb_substep<0, true>(a, b1, b0, A_N0, B_N0);                                                  \
+    } while (0)
+
+    int vb = blockIdx.x, m0, n0;
+    NTP_TILE(vb, m0, n0);
+    NTP_STAGE(0, 0);
+    if (nk > 1) NTP_STAGE(1, 1);
+    bool first = true;
+    for (;;) {
+        bf16x8 a[8], b0[4], b1[4];
+        const int frow = lane & 15, fq = lane >> 4;
+        const unsigned pos0 = ((fq) ^ (lane & 7)) * 16, pos1 = ((4 + fq) ^ (lane & 7)) * 16;
+        const unsigned fa = lds0 + (wm * 128 + frow) * 128, fb = lds0 + B_A + (wn * 64 + frow) * 128;
+        const unsigned fa00 = fa + pos0, fa01 = fa + pos1, fa10 = fa + B_STAGE + pos0, fa11 = fa + B_STAGE + pos1;
+        const unsigned fb00 = fb + pos0, fb01 = fb + pos1, fb10 = fb + B_STAGE + pos0, fb11 = fb + B_STAGE + pos1;
+        ntb_zero<0>();
+        // K-tile 0 of this tile: requested in the prologue (first tile: K-tile 1 is the youngest request and may stay in flight)
+        // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
+        if (first && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7): the loop's counted waits rely on it
+        ntb_read<0>(a[0], fa00); ntb_read<0>(b0[0], fb00); ntb_read<2048>(a[1], fa00); ntb_read<2048>(b0[1], fb00);
+        ntb_read<4096>(a[2], fa00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(a[3], fa00); ntb_read<6144>(b0[3], fb00);
+        ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
+            NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00);
+        }
+        const bool two_left = kt + 1 < nk;
+        if (two_left) NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
+        // last K-tile: sub-step 0 under the reads of sub-step 1; then every read of both stages has retired on every wave (barrier),
+        // so the next tile's first two K-tiles are requested here, under the last 32 MFMAs and the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ntb_substep<0, true>(a, b0, b1, two_left ? fa11 : fa01, two_left ? fb11 : fb01);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int em0 = m0, en0 = n0;
+        vb += gridDim.x;
+        const bool more = vb < ntiles;
+        if (more) {
+            NTP_TILE(vb, m0, n0);
+            NTP_STAGE(0, 0);
+            if (nk > 1) NTP_STAGE(1, 1);
+        }
+        ntb_substep<0, false>(a, b1, b0, 0u, 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
+
+        // ---- epilogue of tile (em0, en0)
+        {
+            const EpiParams& e = p.epi;
+            const int erow = lane >> 3, ecol = (lane & 7) * 8;
+            const int mw = em0 + wm * 128, nw = en0 + wn * 64;
+            NtpEpi c;
+            constexpr int ES = OUT_F32 ? 4 : 2;
+            c.row_bytes_c = (unsigned)(p.ldc * ES);
+            c.c = (char*)p.C + ((int64_t)mw * p.ldc + nw) * ES;
+            c.voff_c = (unsigned)((erow * (int)p.ldc + ecol) * ES);
+            c.aux = nullptr; c.pre = nullptr; c.row_bytes_aux = c.row_bytes_pre = 0; c.voff_aux = c.voff_pre = 0;
+            if constexpr (EPI == NTP_DGELU) {
+                c.row_bytes_aux = (unsigned)(e.ld_aux * 2);
+                c.aux = (const char*)e.dgelu_pre + ((int64_t)mw * e.ld_aux + nw) * 2;
+                c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
+            }
+            if constexpr (EPI == NTP_RESID) {
+                c.row_bytes_aux = (unsigned)(e.ld_aux * 4);
+                c.aux = (const char*)e.resid + ((int64_t)mw * e.ld_aux + nw) * 4;
+                c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 4);
+            }
+            if constexpr (EPI == NTP_GELU_PRE) {
+                c.row_bytes_pre = (unsigned)(e.ld_aux * 2);
+                c.pre = (char*)e.pre_out + ((int64_t)mw * e.ld_aux + nw) * 2;
+                c.voff_pre = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
+            }
+            c.slab = smem + 2 * B_STAGE + wave * P_SLAB;
+            c.slab_wr = smem + 2 * B_STAGE + wave * P_SLAB + frow * 256;
+            c.bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; c.bias1 = c.bias0;
+            if (e.bias) { c.bias0 = *(const f32x4*)(e.bias + nw + ecol); c.bias1 = *(const f32x4*)(e.bias + nw + ecol + 4); }
+            const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;
+            f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+            NtpAux<EPI> x0;
+            if constexpr (EPI == NTP_DGELU || EPI == NTP_RESID) ntp_aux_load<EPI, 0>(x0, c);
+            ntp_epilogue_rows<EPI, 0>(c, lane, x0, do_cs, cs0, cs1);
+            if constexpr (EPI == NTP_DGELU) {
+                if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per (row tile, wave row)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        cs0[j] += __shfl_xor(cs0[j], 8, 64);  cs1[j] += __shfl_xor(cs1[j], 8, 64);
+                        cs0[j] += __shfl_xor(cs0[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64);
+                        cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
+                    }
+                    if (lane < 8) {
+                        float* dst = e.cs_partial + (int64_t)((em0 / B_M) * 2 + wm) * p.N + nw + ecol;
+                        *(f32x4*)dst = cs0;
+                        *(f32x4*)(dst + 4) = cs1;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+    }
+#undef NTP_FULL
+#undef NTP_STAGE
+#undef NTP_TILE
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 // LDS tile: [64 r][128 cols] bf16, 256-B rows.  32-B slot swizzle so that the 8 rows a 32-lane half touches in one
 // ds_read_b64_tr_b16 fall on 8 different 32-B slots of the 256-B bank row.
@@ -788,12 +1067,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
 // in AGPRs this kernel has 128 VGPRs, and 8 running sums + 16 staging registers do not fit next to 64 fragment registers;
 // the launcher runs the separate column-sum pass instead.)
 constexpr int TB_OPER = 32768;   // one operand tile: 64 rows x 512 B
-
-// LDS-DMA with a uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset, written out so that the compiler cannot widen
-// the eight offsets back into eight 64-bit pointers (16 VGPRs this kernel does not have).  M0 = LDS destination of the wave.
-__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");   // M0 is written; this kernel has no compiler-generated M0 user
-}
 
 // Fragments are kept as four dwords: the two 8-byte halves of an operand are joined at dword granularity (a pure register
 // sequence).  With 16-bit element vectors the join is lowered to v_bfi/v_perm read-modify-writes ON the destination registers,
@@ -993,6 +1266,17 @@ void tn_plan(int64_t m, int64_t n, int64_t r, bool colsum, int& kind, int& split
     splits = (int)(s < 1 ? 1 : s);
 }
 
+// CUs of the current device, rounded down to a multiple of 8 (the persistent kernel's grid must keep "blocks b and b + 8 share an
+// XCD" aligned with its virtual block ids)
+int sc_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        return (cus / 8) * 8;
+    }();
+    return n;
+}
+
 }  // namespace
 
 int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c,
@@ -1055,8 +1339,28 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                 p.epi.cs_partial = (float*)epi.colsum_ws;   // [2 * tiles_m][N]; rows past M contribute nothing, every slot is written
                 cs_fused = true;
             }
-            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
-            else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
+            // persistent kernel: whole tiles and one of the step's four epilogues; SC_GEMM_NT=b forces one tile per workgroup (A/B)
+            static const bool one_tile_wg = [] { const char* e = getenv("SC_GEMM_NT"); return e && e[0] == 'b'; }();
+            const EpiParams& pe = p.epi;
+            int kind = -1;
+            const bool aux_ok = epi.ld_aux == ldc && epi.ld_aux < (1 << 22);
+            if (pe.alpha == 1.f && pe.beta == 0.f && m_main % B_M == 0 && n % B_N == 0 && lda < (1 << 22) && ldb < (1 << 22) && ldc < (1 << 22)) {
+                if (out_dtype == SC_F32) {
+                    if (pe.resid && pe.resid_dtype == SC_F32 && !pe.pre_out && pe.act == 0 && !pe.dgelu_pre && !epi.colsum && aux_ok) kind = NTP_RESID;
+                } else if (pe.pre_out && pe.act == 1 && !pe.resid && !pe.dgelu_pre && !epi.colsum && aux_ok) kind = NTP_GELU_PRE;
+                else if (pe.dgelu_pre && !pe.pre_out && pe.act == 0 && !pe.resid && aux_ok && (!epi.colsum || cs_fused)) kind = NTP_DGELU;
+                else if (!pe.dgelu_pre && !pe.pre_out && pe.act == 0 && !pe.resid && !epi.colsum) kind = NTP_BIAS;
+            }
+            if (one_tile_wg || kind < 0) {
+                if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
+            } else {   // one workgroup per CU walks the tile list
+                const unsigned gridp = gridb < (unsigned)sc_num_cus() ? gridb : (unsigned)sc_num_cus();
+                if (kind == NTP_RESID) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_RESID>, dim3(gridp), dim3(512), 0, stream, p);
+                else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_GELU_PRE>, dim3(gridp), dim3(512), 0, stream, p);
+                else if (kind == NTP_DGELU) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_DGELU>, dim3(gridp), dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_BIAS>, dim3(gridp), dim3(512), 0, stream, p);
+            }
             cs_rows_done = m_main;
             if (m_main < m) {   // the remaining rows: same operands and epilogue, pointers advanced by m_main rows
                 GemmBf16Params q = p;

@@ -37,6 +37,9 @@ CONFIGS = {
                        ctx=77, vocab=1000, t_width=64, t_layers=1, t_heads=1),
     "test-l14": dict(embed_dim=64, image_size=224, patch=14, v_width=128, v_layers=1, v_heads=2,
                      ctx=77, vocab=1000, t_width=64, t_layers=1, t_heads=1),
+    # 101 image tokens / 100 text tokens: the sequence lengths between the short (<= 80) and the long (> 128) attention kernels
+    "test-s101": dict(embed_dim=64, image_size=320, patch=32, v_width=128, v_layers=1, v_heads=2,
+                      ctx=100, vocab=1000, t_width=64, t_layers=1, t_heads=1),
 }
 BLOCK_PARAMS = ["ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
                 "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",

@@ -30,7 +30,8 @@ def _pair(pkg, name, precision, seed=3):
     return ref, model
 
 
-@pytest.mark.parametrize("name,precision", [("tiny", "fp32"), ("tiny", "bf16"), ("test-small", "fp32"), ("test-small", "bf16"), ("test-l14", "fp32")])
+@pytest.mark.parametrize("name,precision", [("tiny", "fp32"), ("tiny", "bf16"), ("test-small", "fp32"), ("test-small", "bf16"), ("test-l14", "fp32"),
+                                            ("test-s101", "fp32"), ("test-s101", "bf16")])
 def test_towers_forward_backward(pkg, name, precision):
     from oracle.clip_model import synthetic_batch
     ref, model = _pair(pkg, name, precision)

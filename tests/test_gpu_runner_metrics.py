@@ -63,15 +63,21 @@ def test_uniformity_and_geometry_metrics_on_device(gpu, golden_metrics):
     from sparsify_clip_amd import uniformity as PU
     arr, v = golden_metrics
     f1, f2 = torch.tensor(arr["f1"]).to(gpu), torch.tensor(arr["f2"]).to(gpu)
+    # 1e-4 relative (north_star's fp32 bar): the device covariance (fp32 MFMA GEMM) and rocSOLVER's eigensolvers round differently
+    # from the reference's CPU run; observed 2e-5 on torch_uniformity, <= 1e-5 elsewhere
+    def close(got, key, rel=1e-4):
+        assert abs(got - v[key]) <= rel * abs(v[key]), (key, got, v[key])
+
     got = U.numpy_uniformity(f1, f2)
-    assert isinstance(got, float) and abs(got - v["numpy_uniformity"]) < 1e-5
-    assert abs(U.torch_uniformity(f1, f2).item() - v["torch_uniformity"]) < 1e-5
-    assert abs(U.torch_uniformity1(f1).item() - v["torch_uniformity1"]) < 1e-5
-    assert abs(U.torch_uniformity_equivalent(f1).item() - v["torch_uniformity_equivalent"]) < 1e-5
-    assert abs(U.uniformity10(f1).item() - v["uniformity10"]) < 1e-4
-    assert abs(PU.uniformity(f1, f2) - v["sparsify_clip.uniformity"]) < 1e-5
-    assert abs(PU.compute_gap(f1, f2) - v["compute_gap"]) < 1e-6
-    assert abs(PU.compute_mean_angular_value_of_a_modality(f1) - v["mean_angular_value_f1"]) < 1e-6
+    assert isinstance(got, float)
+    close(got, "numpy_uniformity")
+    close(U.torch_uniformity(f1, f2).item(), "torch_uniformity")
+    close(U.torch_uniformity1(f1).item(), "torch_uniformity1")
+    close(U.torch_uniformity_equivalent(f1).item(), "torch_uniformity_equivalent")
+    close(U.uniformity10(f1).item(), "uniformity10", 2e-4)
+    close(PU.uniformity(f1, f2), "sparsify_clip.uniformity")
+    close(PU.compute_gap(f1, f2), "compute_gap")
+    assert abs(PU.compute_mean_angular_value_of_a_modality(f1) - v["mean_angular_value_f1"]) < 1e-6      # a value of 4e-5: absolute bound
     assert abs(PU.mean_distance_of_true_pairs(f1, f2) - v["mean_distance_of_true_pairs"]) < 1e-6
 
 
