@@ -47,6 +47,7 @@ struct GemmBf16Params {
     float* cs_partial;         // TN: [splits][M] partial column sums when the contraction is split
     float cs_beta;
     int group_m, group_n;      // NT 256x256: tile-walk cell (row tiles x column tiles an XCD's workgroups cover at a time)
+    unsigned long long* stamps;   // diagnostic builds of the persistent NT kernel only (sc_gemm_bf16_nt_stamps): [tile][4] s_memtime values
     EpiParams epi;
 };
 
@@ -735,7 +736,15 @@ __device__ __forceinline__ void ntp_epilogue_rows(const NtpEpi& c, int lane, con
     if constexpr (I + 1 < 8) ntp_epilogue_rows<EPI, I + 1>(c, lane, nxt, do_cs, cs0, cs1);
 }
 
-template <int EPI>
+__device__ __forceinline__ unsigned long long ntp_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
+// STAMP = true is a DIAGNOSTIC instance (tools/gemm_stamps.py): wave 0 records s_memtime at the start of a tile's main loop, at its
+// end, and at the end of the epilogue into p.stamps (a buffer nothing else reads); the production instances contain no stamp.
+template <int EPI, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Params p) {
     __shared__ __attribute__((aligned(1024))) char smem[P_LDS];
     constexpr bool OUT_F32 = EPI == NTP_RESID;
@@ -808,8 +817,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
         // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
         if (first && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+        if constexpr (STAMP) ts0 = ntp_stamp();
         first = false;
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) ts1 = ntp_stamp();
         // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7): the loop's counted waits rely on it
         ntb_read<0>(a[0], fa00); ntb_read<0>(b0[0], fb00); ntb_read<2048>(a[1], fa00); ntb_read<2048>(b0[1], fb00);
         ntb_read<4096>(a[2], fa00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(a[3], fa00); ntb_read<6144>(b0[3], fb00);
@@ -837,6 +849,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
         }
         ntb_substep<0, false>(a, b1, b0, 0u, 0u);
         asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
+        if constexpr (STAMP) ts2 = ntp_stamp();
 
         // ---- epilogue of tile (em0, en0)
         {
@@ -887,6 +900,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
                         *(f32x4*)(dst + 4) = cs1;
                     }
                 }
+            }
+        }
+        if constexpr (STAMP) {
+            ts3 = ntp_stamp();
+            if (t == 0 && p.stamps) {
+                unsigned long long* d = p.stamps + (size_t)(vb - gridDim.x) * 4;
+                d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3;
             }
         }
         if (!more) break;
@@ -1266,6 +1286,8 @@ void tn_plan(int64_t m, int64_t n, int64_t r, bool colsum, int& kind, int& split
     splits = (int)(s < 1 ? 1 : s);
 }
 
+unsigned long long* g_nt_stamps = nullptr;   // diagnostic only (sc_gemm_bf16_nt_stamps); not part of the production path
+
 // CUs of the current device, rounded down to a multiple of 8 (the persistent kernel's grid must keep "blocks b and b + 8 share an
 // XCD" aligned with its virtual block ids)
 int sc_num_cus() {
@@ -1296,6 +1318,7 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     p.M = (int)m; p.N = (int)n; p.K = (int)k;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.splits = 1; p.k_per_split = 0; p.partial = nullptr;
+    p.stamps = g_nt_stamps;
     p.epi = epi;
     p.epi.cs_partial = nullptr;
     bool cs_fused = false;
@@ -1356,6 +1379,12 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                 else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
             } else {   // one workgroup per CU walks the tile list
                 const unsigned gridp = gridb < (unsigned)sc_num_cus() ? gridb : (unsigned)sc_num_cus();
+                if (p.stamps) {   // diagnostic instances
+                    if (kind == NTP_RESID) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_RESID, true>), dim3(gridp), dim3(512), 0, stream, p);
+                    else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_GELU_PRE, true>), dim3(gridp), dim3(512), 0, stream, p);
+                    else if (kind == NTP_DGELU) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_DGELU, true>), dim3(gridp), dim3(512), 0, stream, p);
+                    else hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_BIAS, true>), dim3(gridp), dim3(512), 0, stream, p);
+                } else
                 if (kind == NTP_RESID) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_RESID>, dim3(gridp), dim3(512), 0, stream, p);
                 else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_GELU_PRE>, dim3(gridp), dim3(512), 0, stream, p);
                 else if (kind == NTP_DGELU) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_DGELU>, dim3(gridp), dim3(512), 0, stream, p);
@@ -1413,6 +1442,7 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)r;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.stamps = nullptr;
     SC_REQUIRE(!colsum_a || sc_aligned(colsum_a, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: colsum must be 16-byte aligned");
     int kind;
     tn_plan(m, n, r, colsum_a != nullptr, kind, p.splits);
@@ -1455,6 +1485,10 @@ extern "C" int sc_gemm_bf16_nt(int64_t m, int64_t n, int64_t k, const void* a, i
     SC_TRY(epi_from_abi(e, SC_BF16, epi));
     return sc_gemm_bf16_nt_launch(m, n, k, a, lda, b, ldb, c, ldc, out_dtype, epi, (hipStream_t)stream);
 }
+// Diagnostic hook, deliberately NOT in include/sparsify_hip.h: tools/gemm_stamps.py sets a device buffer ([tiles][4] uint64) that the
+// stamped instances of the persistent NT kernel fill with s_memtime values; NULL (the default) selects the production instances.
+extern "C" void sc_gemm_bf16_nt_stamps(void* buf) { g_nt_stamps = (unsigned long long*)buf; }
+
 extern "C" size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t r) {
     if (m <= 0 || n <= 0 || r <= 0) return 0;
     return sc_gemm_bf16_tn_ws(m, n, r);
