@@ -7,7 +7,7 @@ for d in sys.argv[2:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if flt in r["Kernel_Name"]:
-                name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:48]
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
                 agg[(name, r.get("Grid_Size", r.get("Grid_Size_X", "?")))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (name, grid), cs in sorted(agg.items()):
     vals = {k: sum(v) / len(v) for k, v in cs.items()}

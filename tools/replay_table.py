@@ -24,7 +24,7 @@ print(f"average per call {tot / calls:.1f} us  ->  {flops / (tot * 1e-6) / 1e12:
 # per launch kind, in issue order: the replay runs each (shape, epilogue) `reps` times back to back (after one warm-up in operands())
 names = {}
 for r, d in zip(rows, dur):
-    key = (r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:44], r.get("Grid_Size_X", r.get("Grid_Size", "?")))
+    key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44], r.get("Grid_Size_X", r.get("Grid_Size", "?")))
     names.setdefault(key, []).append(d)
 for (k, g), v in names.items():
     print(f"  {k:44s} grid {g:>8s}: {len(v):4d} dispatches, avg {sum(v) / len(v):8.1f} us")
