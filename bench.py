@@ -55,6 +55,8 @@ def parse():
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-batch", type=int, default=32)
+    p.add_argument("--input-pipeline", type=int, default=0, help="N = 1 only: after the timed region, time the step again with every batch "
+                   "coming through the host assembly + H2D copy + device augmentation of sparsify_clip_amd/input_pipeline.py (uint8 COCO-sized images)")
     p.add_argument("--simulate-dp", type=int, default=8, help="N = 1 only: after the timed region, time the step again with the loss head fed a "
                    "global batch of simulate_dp x local_batch rows (filler rows for the absent ranks) = the per-GPU work of that DP job; 1 = off")
     return p.parse_args()
@@ -263,6 +265,25 @@ def main():
         out["dp_rank_equivalent"] = {"simulated_world": args.simulate_dp, "loss_head_batch": args.simulate_dp * args.local_batch,
                                      "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
                                      "note": "compute of one rank of the DP job (global-batch loss head replicated), collectives excluded"}
+    if world == 1 and args.input_pipeline:
+        # the same step fed by the real input path: uint8 pixels -> pinned staging -> H2D on a side stream -> device crop/resize/flip/normalise
+        from sparsify_clip_amd.input_pipeline import DeviceAugLoader, SyntheticCocoDataset
+        nsteps = min(args.steps, 8)
+        loader = DeviceAugLoader(SyntheticCocoDataset((nsteps + 2) * args.local_batch, seed=7), args.local_batch, device, train=True, seed=7,
+                                 size=c["image_size"], workers=host_threads(), tokenizer=trainer.tokenizer)
+        it = iter(loader)
+        for _ in range(2):
+            trainer.step(*next(it))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nsteps):
+            trainer.step(*next(it))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / nsteps
+        del it
+        out["with_input_pipeline"] = {"ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(args.local_batch / dt, 1), "host_threads": host_threads(),
+                                      "note": "uint8 640x480-class images: host crop-box sampling + packing, H2D (PCIe) on a copy stream, device "
+                                              "RandomResizedCrop/HFlip/Normalize and host tokenisation, all inside the timed loop"}
     if world > 1:
         # the ranks part here: rank 0's roofline replay runs alone, nobody sits in a collective with a timeout meanwhile
         tdist.barrier()

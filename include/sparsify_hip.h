@@ -242,6 +242,21 @@ int sc_block_bwd_async(const sc_block_desc* d, const float* dx_out, const void* 
                        void* side_stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input stage on the device: the reference's image transforms (sparsify_clip.py:1003-1016) from raw uint8 RGB pixels to the
+ * normalised fp32 [N,3,S,S] batch:  train = RandomResizedCrop((S,S)) -> RandomHorizontalFlip -> ToTensor -> Normalize(mean,std),
+ * test = Resize((S,S)) -> ToTensor -> Normalize.  "Resize" is Pillow's antialiased two-pass BILINEAR resampler (what torchvision
+ * runs on the PIL images of CocoCaptions), restated bit for bit: 22-bit fixed-point taps, 8-bit intermediate image.
+ *   src        packed uint8 images, HWC interleaved RGB; image n starts at byte offset[n]
+ *   dims       int32 [N][6] = {H, W, top, left, h, w}: full size and the crop box (the whole image for Resize)
+ *   flip       int32 [N] (may be NULL): != 0 mirrors the resized image horizontally
+ *   tmp        uint8 workspace; image n's intermediate (h x S x 3 bytes) lives at tmp_offset[n]; max_box_h = max_n h
+ * All arrays are DEVICE memory; the random crop boxes / flips are drawn on the host (reference :1009-1010 via torchvision). */
+int sc_image_resample_normalize(const uint8_t* src, const int64_t* offset, const int32_t* dims, const int32_t* flip,
+                                const int64_t* tmp_offset, int64_t n, int64_t max_box_h, int64_t out_size,
+                                float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b,
+                                void* tmp, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.AdamW defaults over one flat fp32 parameter buffer (sparsify_clip.py:730, :962/966).
  * p *= 1 - lr*wd; m,v moments; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `step` is the 1-based step count.
  * shadow_bf16 (may be NULL) receives a bf16 copy of the updated parameters.

@@ -50,7 +50,7 @@ class BlockDesc(ctypes.Structure):
 
 
 _CTYPES = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
-           "size_t": ctypes.c_size_t}
+           "size_t": ctypes.c_size_t, "uint8_t": ctypes.c_uint8}
 
 
 def parse_header(path: str = HEADER):

@@ -19,7 +19,11 @@ REQUIRED_KEYS = ["project_name", "run_name", "seed", "learning_rate", "batch_siz
                  "epochs", "loss_type", "only_lunif_epochs", "anchor_temperature", "anchor_temperature_learnable",
                  "save_checkpoint_every_n_epochs", "resume_checkpoint", "fp16"]
 # build-side keys (not in the reference schema); all default to "behave like the reference"
-EXTRA_DEFAULTS = {"precision": None, "synthetic": True, "eval_batch_size": None, "dp": 1, "log_every": 10, "steps_per_epoch": None}
+# synthetic: True = no COCO on disk (False reads ./data/coco/... exactly like the reference, :995-1001);
+# input_pipeline: "resident" = pre-normalised fp32 batches already in HBM (the benchmark's contract), "device" = uint8 pixels through
+# the host assembly + H2D copy + device augmentation of input_pipeline.py (always used when synthetic is False)
+EXTRA_DEFAULTS = {"precision": None, "synthetic": True, "eval_batch_size": None, "dp": 1, "log_every": 10, "steps_per_epoch": None,
+                  "input_pipeline": "resident", "full_state_checkpoint": False}
 
 
 def load_config(path: str, device_id: int = 0, overrides: dict | None = None):

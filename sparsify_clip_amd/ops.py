@@ -297,6 +297,17 @@ def pool_scatter(d_out, idx, batch, seq, dx):
     return dx
 
 
+def image_resample_normalize(pixels, offset, dims, flip, tmp_offset, n, max_box_h, tmp_bytes, size, mean, std, out=None):
+    """uint8 crop boxes -> normalised fp32 [n,3,size,size] (csrc/augment.hip); every array argument is a device tensor."""
+    require_gpu(pixels, "pixels", torch.uint8)
+    if out is None:
+        out = torch.empty(n, 3, size, size, dtype=torch.float32, device=pixels.device)
+    tmp = _workspace(int(tmp_bytes), pixels.device, "aug")
+    LIB.call("sc_image_resample_normalize", ptr(pixels), ptr(offset), ptr(dims), ptr(flip), ptr(tmp_offset), int(n), int(max_box_h), int(size),
+             float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), ptr(tmp), ptr(out), stream_ptr())
+    return out
+
+
 def cast_bf16(src, dst=None):
     require_gpu(src, "src", torch.float32)
     if dst is None:

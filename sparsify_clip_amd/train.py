@@ -174,7 +174,11 @@ def evaluate_model(model, test_loader, device, plot_embeddings=False, logger=Non
 
 
 def dataset_loader(config, device):
-    """Synthetic stand-in for the reference's COCO loaders (:992-1065): same (train, test) pair, drop_last semantics."""
+    """The reference's dataset_loader(config) (:992-1065): (train, test) loaders with drop_last semantics.
+      * synthetic: False  -> COCO captions from ./data/coco/... (the reference's paths), decoded on the host, cropped / resized /
+        flipped / normalised ON THE DEVICE (input_pipeline.DeviceAugLoader); every rank reads its rank-major share of each batch;
+      * input_pipeline: "device" -> the same pipeline fed by a synthetic uint8 dataset of COCO-like image sizes;
+      * otherwise (default) -> pre-normalised fp32 batches resident in HBM (SyntheticLoader)."""
     world, rank = D.world_size(), D.get_rank()
     gb = config["batch_size"]
     if gb % world:
@@ -183,12 +187,42 @@ def dataset_loader(config, device):
     if config.get("steps_per_epoch"):
         n_train = config["steps_per_epoch"] * gb
     n_test = config["num_test_samples"] if config["num_test_samples"] != -1 else 5000
-    eb = config.get("eval_batch_size") or min(gb, n_test)
     from .model import CONFIGS, canonical_name
     c = CONFIGS[canonical_name(config["model"])]
+    if not config.get("synthetic", True) or config.get("input_pipeline") == "device":
+        from . import input_pipeline as IP
+        if not config.get("synthetic", True):
+            troot, tann = IP.coco_paths("train")
+            vroot, vann = IP.coco_paths("test")
+            if not (os.path.exists(tann) and os.path.exists(vann)):
+                raise ScError(f"synthetic: False needs the reference's COCO layout ({tann}, {vann}); it is not on this machine")
+            train_ds = IP.CocoCaptionsDataset(troot, tann, config["num_train_samples"])
+            test_ds = IP.CocoCaptionsDataset(vroot, vann, config["num_test_samples"])
+        else:
+            train_ds, test_ds = IP.SyntheticCocoDataset(n_train, config["seed"]), IP.SyntheticCocoDataset(n_test, config["seed"] + 777)
+        eb = config.get("eval_batch_size") or min(gb, len(test_ds))
+        train = IP.DeviceAugLoader(_RankShard(train_ds, gb, rank, world), gb // world, device, train=True, seed=config["seed"], size=c["image_size"])
+        test = IP.DeviceAugLoader(test_ds, eb, device, train=False, seed=config["seed"] + 777, size=c["image_size"])
+        return train, test
+    eb = config.get("eval_batch_size") or min(gb, n_test)
     train = SyntheticLoader(n_train // world, gb // world, config["seed"] + 1000 * rank, device, c["image_size"], c["ctx"], c["vocab"])
     test = SyntheticLoader(n_test, eb, config["seed"] + 777, device, c["image_size"], c["ctx"], c["vocab"], distinct=max(1, n_test // eb))
     return train, test
+
+
+class _RankShard:
+    """View of a dataset for one data-parallel rank: of every global batch of `gb` consecutive samples the rank sees its
+    rank-major slice (world = 1: the dataset itself).  Shuffling then happens inside the rank's share with the same seed on every
+    rank, so a global batch is never split differently on two ranks."""
+
+    def __init__(self, ds, gb, rank, world):
+        self.ds, self.per, self.gb, self.rank, self.world = ds, gb // world, gb, rank, world
+
+    def __len__(self):
+        return (len(self.ds) // self.gb) * self.per
+
+    def __getitem__(self, i):
+        return self.ds[(i // self.per) * self.gb + self.rank * self.per + i % self.per]
 
 
 def train_model(config, train_loader, test_loader, device, logger=None):

@@ -209,3 +209,42 @@ def test_asm_audit_flags_the_three_hazards():
     assert audit(kernel(loop + "\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v10, 0\n")) == []
     # other kernels in the same file are not audited
     assert audit(".globl _Z5otherv\n_Z5otherv:\n\tscratch_store_dword off, v3, off\n\ts_endpgm\n.Lfunc_end1:\n") == []
+
+
+def test_input_pipeline_host_side(tmp_path):
+    """Host logic of the input stage: the crop-box sampler == the oracle's restatement of torchvision's get_params (same draws from
+    one Philox stream, boxes inside the image, the centre-crop fallback), and the COCO captions reader (sorted ids, Subset limit,
+    captions per image) on a fixture in the reference's directory layout."""
+    import json
+    from PIL import Image
+    from oracle import input_pipeline as O
+    from sparsify_clip_amd import input_pipeline as IP
+    for seed, (h, w) in enumerate([(480, 640), (640, 480), (50, 1000), (1000, 40), (7, 9)]):
+        a = np.random.Generator(np.random.Philox(seed))
+        b = np.random.Generator(np.random.Philox(seed))
+        for _ in range(50):
+            box = IP.random_resized_crop_params(a, h, w)
+            assert box == O.random_resized_crop_params(b, h, w)
+            top, left, bh, bw = box
+            assert 0 <= top and 0 <= left and 0 < bh and 0 < bw and top + bh <= h and left + bw <= w
+    # an impossible scale forces the fallback: whole image when the aspect ratio is admissible, clamped otherwise
+    rng = np.random.Generator(np.random.Philox(0))
+    assert IP.random_resized_crop_params(rng, 100, 120, scale=(4.0, 5.0)) == (0, 0, 100, 120)
+    assert IP.random_resized_crop_params(rng, 100, 400, scale=(4.0, 5.0)) == (0, (400 - 133) // 2, 100, 133)
+    assert IP.MEAN == O.MEAN and IP.STD == O.STD
+    root = tmp_path / "imgs"
+    root.mkdir()
+    images, anns = [], []
+    for iid in (30, 10, 20):
+        Image.fromarray(np.full((4 + iid // 10, 6, 3), iid, dtype=np.uint8), "RGB").save(root / f"{iid}.png")
+        images.append({"id": iid, "file_name": f"{iid}.png"})
+        anns += [{"image_id": iid, "id": iid * 10 + c, "caption": f"c{c}-{iid}"} for c in range(3)]
+    ann = tmp_path / "captions.json"
+    ann.write_text(json.dumps({"images": images, "annotations": anns}))
+    ds = IP.CocoCaptionsDataset(str(root), str(ann))
+    assert len(ds) == 3 and [int(ds[i][0][0, 0, 0]) for i in range(3)] == [10, 20, 30]
+    assert ds[1][1] == ["c0-20", "c1-20", "c2-20"] and ds[2][0].shape == (7, 6, 3) and ds[0][0].dtype == np.uint8
+    assert len(IP.CocoCaptionsDataset(str(root), str(ann), limit=2)) == 2
+    syn = IP.SyntheticCocoDataset(10, seed=1, pool=4)
+    img, caps = syn[7]
+    assert img.dtype == np.uint8 and img.ndim == 3 and len(caps) == 5 and syn[7][1] == caps
