@@ -74,15 +74,14 @@ class SyntheticCocoDataset:
         rng = np.random.Generator(np.random.Philox(seed))
         self.n = n
         self.pool = [rng.integers(0, 256, size=(*self.SIZES[k % len(self.SIZES)], 3), dtype=np.uint8) for k in range(min(pool, max(n, 1)))]
-        self.seed = seed
+        self.caps = [[" ".join(self.WORDS[j] for j in rng.integers(0, len(self.WORDS), size=int(rng.integers(5, 16)))) for _ in range(5)]
+                     for _ in range(997)]      # a caption set per (index mod 997): cheap to serve, not periodic with the image pool
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
-        rng = np.random.Generator(np.random.Philox(self.seed * 7919 + i))
-        caps = [" ".join(self.WORDS[j] for j in rng.integers(0, len(self.WORDS), size=int(rng.integers(5, 16)))) for _ in range(5)]
-        return self.pool[i % len(self.pool)], caps
+        return self.pool[i % len(self.pool)], self.caps[i % 997]
 
 
 # ------------------------------------------------------------------------------------------------ host-side geometry
@@ -138,23 +137,28 @@ class DeviceAugLoader:
         return self.n_batches
 
     # ---- host side
-    def _sample(self, idx: int, rng: np.random.Generator):
-        img, caps = self.ds[idx]
+    def _geometry(self, img, caps, rng: np.random.Generator):
+        """The random draws of one sample, in the reference's order: crop box (:1009), flip (:1010), caption choice (:1055)."""
         h, w = img.shape[0], img.shape[1]
         if self.train:
-            top, left, bh, bw = random_resized_crop_params(rng, h, w)      # :1009
-            flip = int(rng.random() < 0.5)                                  # :1010
+            top, left, bh, bw = random_resized_crop_params(rng, h, w)
+            flip = int(rng.random() < 0.5)
         else:
             top, left, bh, bw, flip = 0, 0, h, w, 0                         # :1014 Resize((224,224))
         if bh > 31 * self.size or bw > 31 * self.size:
-            raise ScError(f"image {idx}: a {bh}x{bw} box is more than a 31x down-scale to {self.size} (kernel tap limit)")
-        cap = caps[int(rng.integers(0, len(caps)))]                         # random.choice(list_captions) :1055
+            raise ScError(f"a {bh}x{bw} box is more than a 31x down-scale to {self.size} (kernel tap limit)")
+        cap = caps[int(rng.integers(0, len(caps)))]
         return img[top:top + bh, left:left + bw], flip, cap
+
+    def batch_rng(self, batch_index: int) -> np.random.Generator:
+        """One Philox stream per (seed, epoch, batch): samples consume it in batch order, whatever the number of worker threads."""
+        return np.random.Generator(np.random.Philox([self.seed, self.epoch * (1 << 32) + batch_index]))
 
     def _assemble(self, batch_index: int, order, pool: ThreadPoolExecutor, pinned: torch.Tensor) -> _HostBatch:
         ids = order[batch_index * self.bs:(batch_index + 1) * self.bs]
-        rngs = [np.random.Generator(np.random.Philox([self.seed, self.epoch * (1 << 32) + int(i)])) for i in ids]
-        samples = list(pool.map(lambda a: self._sample(int(a[0]), a[1]), zip(ids, rngs)))
+        items = list(pool.map(lambda i: self.ds[int(i)], ids))              # decode in parallel
+        rng = self.batch_rng(batch_index)
+        samples = [self._geometry(img, caps, rng) for img, caps in items]   # cheap scalar draws, sequential = deterministic
         hb = _HostBatch()
         hb.n = len(samples)
         sizes = np.array([s[0].shape[0] * s[0].shape[1] * 3 for s in samples], dtype=np.int64)

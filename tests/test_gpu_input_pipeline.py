@@ -70,9 +70,9 @@ def test_loader_train_and_eval_match_the_cpu_pipeline(gpu):
         c = DeviceAugLoader(ds, 16, gpu, train=train, seed=5)
         rng = np.random.Generator(np.random.Philox([5, 1000003]))
         order = rng.permutation(len(ds)) if train else np.arange(len(ds))
+        r = c.batch_rng(0)
         for k, idx in enumerate(order[:16]):
-            r = np.random.Generator(np.random.Philox([5, int(idx)]))
-            crop, flip, cap = c._sample(int(idx), r)
+            crop, flip, cap = c._geometry(*ds[int(idx)], r)
             want = resized_crop_normalize(np.ascontiguousarray(crop), (0, 0, crop.shape[0], crop.shape[1]), bool(flip), 224)
             assert torch.equal(ba[0][0][k].cpu(), want), (train, k)
             assert cap == ba[0][1][k] and cap in ds[int(idx)][1]
