@@ -131,6 +131,15 @@ int sc_axpy_f32(int64_t n, float alpha, const float* x, float* y, void* stream);
 int sc_retrieval_ranks(const float* score, int64_t n, int32_t* rank_fwd, int32_t* rank_bwd,
                        int32_t* top1_fwd, int32_t* top1_bwd, void* stream);
 
+/* Eval geometry + recall counts in one call, no [N,N] matrix and no host round trip per metric (sparsify_clip.py:418-436 compute_gap,
+ * :438-457 mean angular value, :508-528 mean cosine of true pairs, :382-392 / :404-414 R@1/5/10):
+ *   out10[0] = | mean_i img_i - mean_i txt_i |                out10[3] = mean_i <img_i, txt_i>
+ *   out10[1] = mean_{i != j} <img_i, img_j>   out10[2] = same for txt   (via |sum_i x_i|^2 - sum_i |x_i|^2)
+ *   out10[4..6] / out10[7..9] = #queries with rank < 1 / 5 / 10 in rank_fwd / rank_bwd (either may be NULL -> zeros) */
+size_t sc_eval_metrics_workspace_bytes(int64_t n, int64_t e);
+int sc_eval_metrics(const float* img, const float* txt, int64_t n, int64_t e, const int32_t* rank_fwd, const int32_t* rank_bwd,
+                    float* out10, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Encoder building blocks (open_clip ViT / text transformer)
  * `dtype` is the activation/GEMM-operand dtype (SC_BF16 or SC_F32); the residual stream, LayerNorm

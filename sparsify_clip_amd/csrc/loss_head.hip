@@ -323,6 +323,62 @@ __global__ __launch_bounds__(256) void retrieval_kernel(const float* s, int64_t 
     }
 }
 
+// ----------------------------------------------------------------------------- eval geometry metrics (sparsify_clip.py:418-457, :508-528, :382-414)
+// per row i: <a_i, b_i>, |a_i|^2, |b_i|^2   (one wave per row)
+__global__ __launch_bounds__(256) void eval_row_stats_kernel(const float* a, const float* b_, int64_t n, int64_t e, float* rowstat /*[3][n]*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float d = 0.f, na = 0.f, nb = 0.f;
+    for (int64_t j = lane; j < e; j += 64) {
+        const float x = a[row * e + j], y = b_[row * e + j];
+        d += x * y; na += x * x; nb += y * y;
+    }
+    d = wave_sum(d); na = wave_sum(na); nb = wave_sum(nb);
+    if (lane == 0) { rowstat[row] = d; rowstat[n + row] = na; rowstat[2 * n + row] = nb; }
+}
+// column sums over a chunk of rows: thread = column, blockIdx.y = chunk; part[chunk][which][e]
+__global__ __launch_bounds__(256) void eval_col_partial_kernel(const float* a, const float* b_, int64_t n, int64_t e, int64_t rows_per_chunk, float* part) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= e) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    float sa = 0.f, sb = 0.f;
+    for (int64_t r = r0; r < r1; ++r) { sa += a[r * e + col]; sb += b_[r * e + col]; }
+    part[((int64_t)blockIdx.y * 2 + 0) * e + col] = sa;
+    part[((int64_t)blockIdx.y * 2 + 1) * e + col] = sb;
+}
+// out[0] gap = |mean(a) - mean(b)|; out[1], out[2] mean off-diagonal cosine of a / b = (|sum_i x_i|^2 - sum_i |x_i|^2) / (n (n-1)) (the sum of
+// all n^2 Gram entries is the squared norm of the sum vector: no [n,n] matrix); out[3] mean <a_i, b_i>;
+// out[4..6] / out[7..9]: number of queries whose true match has rank < 1 / 5 / 10, forward / backward
+__global__ __launch_bounds__(256) void eval_final_kernel(const float* part, int chunks, const float* rowstat, const int32_t* rank_f, const int32_t* rank_b,
+                                                         int64_t n, int64_t e, float* out) {
+    __shared__ float sm[4];
+    float gap2 = 0.f, sa2 = 0.f, sb2 = 0.f;
+    for (int64_t col = threadIdx.x; col < e; col += 256) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = 0; c < chunks; ++c) { sa += part[((int64_t)c * 2 + 0) * e + col]; sb += part[((int64_t)c * 2 + 1) * e + col]; }
+        const float d = (sa - sb) / (float)n;
+        gap2 += d * d; sa2 += sa * sa; sb2 += sb * sb;
+    }
+    gap2 = block_sum_256(gap2, sm); sa2 = block_sum_256(sa2, sm); sb2 = block_sum_256(sb2, sm);
+    float dot = 0.f, na = 0.f, nb = 0.f, cf[3] = {0.f, 0.f, 0.f}, cb[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        dot += rowstat[i]; na += rowstat[n + i]; nb += rowstat[2 * n + i];
+        if (rank_f) { const int r = rank_f[i]; cf[0] += r < 1; cf[1] += r < 5; cf[2] += r < 10; }
+        if (rank_b) { const int r = rank_b[i]; cb[0] += r < 1; cb[1] += r < 5; cb[2] += r < 10; }
+    }
+    dot = block_sum_256(dot, sm); na = block_sum_256(na, sm); nb = block_sum_256(nb, sm);
+    for (int k = 0; k < 3; ++k) { cf[k] = block_sum_256(cf[k], sm); cb[k] = block_sum_256(cb[k], sm); }
+    if (threadIdx.x == 0) {
+        const float pairs = (float)n * (float)(n - 1);
+        out[0] = sqrtf(gap2);
+        out[1] = (sa2 - na) / pairs;
+        out[2] = (sb2 - nb) / pairs;
+        out[3] = dot / (float)n;
+        for (int k = 0; k < 3; ++k) { out[4 + k] = cf[k]; out[7 + k] = cb[k]; }
+    }
+}
+
 inline unsigned rows4(int64_t b) { return (unsigned)sc_cdiv(b, 4); }
 inline int red_blocks(int64_t b) { return (int)min((int64_t)RED_BLOCKS, sc_cdiv(b, 4)); }
 
@@ -464,6 +520,26 @@ extern "C" int sc_retrieval_ranks(const float* score, int64_t n, int32_t* rank_f
                                   void* stream_) {
     SC_REQUIRE(score && rank_fwd && rank_bwd && top1_fwd && top1_bwd && n > 0, SC_ERR_ARG, "sc_retrieval_ranks: bad argument");
     hipLaunchKernelGGL(retrieval_kernel, dim3(rows4(n)), dim3(256), 0, (hipStream_t)stream_, score, n, rank_fwd, rank_bwd, top1_fwd, top1_bwd);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" size_t sc_eval_metrics_workspace_bytes(int64_t n, int64_t e) {
+    if (n <= 0 || e <= 0) return 0;
+    return ((size_t)3 * n + (size_t)64 * 2 * e) * sizeof(float);
+}
+extern "C" int sc_eval_metrics(const float* img, const float* txt, int64_t n, int64_t e, const int32_t* rank_fwd, const int32_t* rank_bwd, float* out10,
+                               void* ws, size_t ws_bytes, void* stream_) {
+    SC_REQUIRE(img && txt && out10 && ws && n >= 2 && e >= 1, SC_ERR_ARG, "sc_eval_metrics: bad argument");
+    SC_REQUIRE(ws_bytes >= sc_eval_metrics_workspace_bytes(n, e) && sc_aligned(ws, 16), SC_ERR_WORKSPACE, "sc_eval_metrics: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    float* rowstat = (float*)ws;
+    float* part = rowstat + 3 * n;
+    const int chunks = (int)min((int64_t)64, sc_cdiv(n, 64));
+    const int64_t rpc = sc_cdiv(n, chunks);
+    hipLaunchKernelGGL(eval_row_stats_kernel, dim3(rows4(n)), dim3(256), 0, st, img, txt, n, e, rowstat);
+    hipLaunchKernelGGL(eval_col_partial_kernel, dim3((unsigned)sc_cdiv(e, 256), chunks), dim3(256), 0, st, img, txt, n, e, rpc, part);
+    hipLaunchKernelGGL(eval_final_kernel, dim3(1), dim3(256), 0, st, part, chunks, rowstat, rank_fwd, rank_bwd, n, e, out10);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }

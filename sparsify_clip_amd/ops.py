@@ -185,6 +185,16 @@ def retrieval_ranks(score):
     return outs  # rank_fwd, rank_bwd, top1_fwd, top1_bwd
 
 
+def eval_metrics(img, txt, rank_fwd=None, rank_bwd=None):
+    """-> device fp32 [10]: gap, mean angular (img, txt), mean true-pair cosine, R@1/5/10 hit counts forward / backward."""
+    require_gpu(img, "img", torch.float32), require_gpu(txt, "txt", torch.float32)
+    n, e = img.shape
+    out = torch.empty(10, dtype=torch.float32, device=img.device)
+    ws = _workspace(LIB.raw("sc_eval_metrics_workspace_bytes")(n, e), img.device, "eval")
+    LIB.call("sc_eval_metrics", ptr(img), ptr(txt), n, e, ptr(rank_fwd), ptr(rank_bwd), ptr(out), ptr(ws), ws.numel(), stream_ptr())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ encoder pieces
 def layernorm_fwd(x, gamma, beta, out_dtype, out=None):
     require_gpu(x, "x", torch.float32)

@@ -128,6 +128,37 @@ class Trainer:
             self.flush_logs()
         return res.loss
 
+    # ---- optional full-state sidecar (the reference resumes WEIGHTS only, :719-724; SURVEY 5.4 asks for an opt-in sidecar)
+    def full_state(self) -> dict:
+        """Everything besides the weights that a bit-exact continuation needs, as a flat {str: Tensor} (weights_only-loadable)."""
+        opt = self.optimizer
+        st = {"adam_m": opt.m.detach().cpu(), "adam_v": opt.v.detach().cpu(),
+              "counters": torch.tensor([opt.steps, self.current_batch, self.epoch, self.scheduler.last_epoch], dtype=torch.int64),
+              "weights": torch.tensor([self.beta, self.alpha], dtype=torch.float64)}
+        if self.learnable_t:
+            val, grad, em, ev = opt.extra_state[id(self.temperature)]
+            st.update(temperature=self.temperature.detach().cpu().reshape(1), temperature_m=em.cpu(), temperature_v=ev.cpu(),
+                      temperature_steps=torch.tensor([opt.extra_steps[id(self.temperature)]], dtype=torch.int64))
+        return st
+
+    def load_full_state(self, st: dict):
+        opt = self.optimizer
+        if st["adam_m"].numel() != opt.m.numel():
+            raise ScError("full-state sidecar belongs to a different model (moment size mismatch)")
+        opt.m.copy_(st["adam_m"]), opt.v.copy_(st["adam_v"])
+        opt.steps, self.current_batch, self.epoch, last = (int(v) for v in st["counters"])
+        self.beta, self.alpha = (float(v) for v in st["weights"])
+        self.scheduler.last_epoch = last
+        lrs = [base * lmbda(last) for lmbda, base in zip(self.scheduler.lr_lambdas, self.scheduler.base_lrs)]
+        for g, lr in zip(opt.param_groups, lrs):
+            g["lr"] = lr
+        self.scheduler._last_lr = lrs
+        if self.learnable_t and "temperature" in st:
+            self.temperature.data.copy_(st["temperature"].reshape(()))
+            val, grad, em, ev = opt.extra_state[id(self.temperature)]
+            em.copy_(st["temperature_m"]), ev.copy_(st["temperature_v"])
+            opt.extra_steps[id(self.temperature)] = int(st["temperature_steps"])
+
     def flush_logs(self):
         for loss, row in self.pending_logs:
             self.logger.log({"train_loss": float(loss.item()), **row})
@@ -161,12 +192,20 @@ def evaluate_model(model, test_loader, device, plot_embeddings=False, logger=Non
     txt, _ = ops.l2norm_fwd(torch.cat(txts), 0.0)
     score = ops.gemm_f32(txt, img, trans_b=True)        # [N_text, N_image]  :628
     rank_f, rank_b, top_f, top_b = ops.retrieval_ranks(score)
-    final_log = {**recall_from_ranks(rank_f, "forward"), **recall_from_ranks(rank_b, "backward"),
-                 "gap": round(U.compute_gap(img, txt), 4),
-                 "mean_angular_value_image": round(U.compute_mean_angular_value_of_a_modality(img), 4),
-                 "mean_angular_value_text": round(U.compute_mean_angular_value_of_a_modality(txt), 4),
+    n = score.shape[0]
+    m = ops.eval_metrics(img, txt, rank_f, rank_b).tolist()      # ONE read-back for gap / angular / true-pair cosine / recall counts
+
+    def recall(counts, prefix):      # reference :382-392 rounding
+        r = [c / n for c in counts]
+        return {f"{prefix}_r1": round(r[0] * 100, 4), f"{prefix}_r5": round(r[1] * 100, 4), f"{prefix}_r10": round(r[2] * 100, 4),
+                f"{prefix}_ravg": round(sum(r) / 3 * 100, 4)}
+
+    final_log = {**recall(m[4:7], "forward"), **recall(m[7:10], "backward"),
+                 "gap": round(m[0], 4),
+                 "mean_angular_value_image": round(m[1], 4),
+                 "mean_angular_value_text": round(m[2], 4),
                  "uniformity": round(U.uniformity(img, txt), 4),
-                 "mean_cosine_similarity_true_pairs": round(U.mean_distance_of_true_pairs(img, txt), 4)}
+                 "mean_cosine_similarity_true_pairs": round(m[3], 4)}
     if logger is not None:
         logger.log(final_log)
     model.train(was_training)
@@ -233,6 +272,11 @@ def train_model(config, train_loader, test_loader, device, logger=None):
     if config["resume_checkpoint"]:   # :719-724 (weights only, `module.`-prefixed keys accepted)
         model.load_state_dict(torch.load(config["resume_checkpoint"], map_location="cpu", weights_only=True))
         start_epoch = config.get("resume_epoch", 0)
+        sidecar = sidecar_path(config["resume_checkpoint"])
+        if os.path.exists(sidecar):   # optimiser moments, step counters, schedule position, temperature: continue where the run stopped
+            trainer.load_full_state(torch.load(sidecar, map_location="cpu", weights_only=True))
+            trainer.optimizer.model.refresh_shadows(full=True)
+            start_epoch = trainer.epoch + 1
     if len(train_loader) == 0:
         raise ScError("training loader yields no batches (num_train_samples < batch_size with drop_last, SURVEY 0.10)")
     evaluate_model(model, test_loader, device, logger=logger)   # :740
@@ -244,8 +288,17 @@ def train_model(config, train_loader, test_loader, device, logger=None):
         evaluate_model(model, test_loader, device, logger=logger)   # :980
         if (epoch + 1) % config["save_checkpoint_every_n_epochs"] == 0 and D.get_rank() == 0:   # :982-984
             os.makedirs("models", exist_ok=True)
-            torch.save(model.state_dict(prefix="module."), f"models/{config['run_name']}_epoch_{epoch + 1}.pt")
+            path = f"models/{config['run_name']}_epoch_{epoch + 1}.pt"
+            torch.save(model.state_dict(prefix="module."), path)
+            if config.get("full_state_checkpoint"):
+                torch.save(trainer.full_state(), sidecar_path(path))
     return model
+
+
+def sidecar_path(checkpoint_path: str) -> str:
+    """models/run_epoch_3.pt -> models/run_epoch_3.state.pt"""
+    root, ext = os.path.splitext(checkpoint_path)
+    return root + ".state" + ext
 
 
 def main(config):

@@ -97,23 +97,36 @@ def uniformity(features_modality1, features_modality2):
     return numpy_uniformity(features_modality1, features_modality2)
 
 
+def _device_metrics(a, b):
+    """GPU fp32 inputs: all geometry metrics from ONE library call (sc_eval_metrics), else None."""
+    if a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and a.shape == b.shape and a.shape[0] >= 2:
+        from . import ops
+        return ops.eval_metrics(a.contiguous(), b.contiguous())
+    return None
+
+
 def compute_gap(feat_modality1, feat_modality2):
     """sparsify_clip.py:418-436."""
+    m = _device_metrics(feat_modality1, feat_modality2)
+    if m is not None:
+        return m[0].item()
     return torch.norm(feat_modality1.mean(dim=0) - feat_modality2.mean(dim=0)).item()
 
 
 def compute_mean_angular_value_of_a_modality(feat_modality):
-    """Mean off-diagonal cosine.  sparsify_clip.py:438-457."""
-    x = feat_modality.contiguous()
-    if x.is_cuda and x.dtype == torch.float32:
-        from . import ops
-        g = ops.gemm_f32(x, x, trans_b=True)
-    else:
-        g = x @ x.T
+    """Mean off-diagonal cosine.  sparsify_clip.py:438-457 (the reference builds the [N,N] Gram matrix; the sum of all its entries is
+    |sum_i x_i|^2, so the device path needs O(N E) work and no matrix)."""
+    m = _device_metrics(feat_modality, feat_modality)
+    if m is not None:
+        return m[1].item()
+    g = feat_modality @ feat_modality.T
     n = g.size(0)
     return ((g.sum() - torch.diagonal(g).sum()) / (n * (n - 1))).item()
 
 
 def mean_distance_of_true_pairs(features_modality1, features_modality2):
     """Mean cosine of matching pairs.  sparsify_clip.py:508-528."""
+    m = _device_metrics(features_modality1, features_modality2)
+    if m is not None:
+        return m[3].item()
     return (features_modality1 * features_modality2).sum(dim=1).mean().item()

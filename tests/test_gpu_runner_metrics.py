@@ -99,6 +99,13 @@ def test_recall_dicts_from_device_ranks(gpu, golden_metrics):
     want_f, want_b = M.retrieval_metrics(hard, "forward"), M.retrieval_metrics(hard, "backward")
     assert 0.0 < want_f["forward_r1"] < 100.0
     assert recall_from_ranks(rank_f, "forward") == want_f and recall_from_ranks(rank_b, "backward") == want_b
+    # the fused device call evaluate_model uses (sc_eval_metrics): recall hit counts and the geometry metrics in one read-back
+    m = ops.eval_metrics(f1.to(gpu), f2.to(gpu), rank_f, rank_b).tolist()
+    n = f1.shape[0]
+    assert [round(c / n * 100, 4) for c in m[4:7]] == [want_f["forward_r1"], want_f["forward_r5"], want_f["forward_r10"]]
+    assert [round(c / n * 100, 4) for c in m[7:10]] == [want_b["backward_r1"], want_b["backward_r5"], want_b["backward_r10"]]
+    assert abs(m[0] - v["compute_gap"]) < 1e-6 and abs(m[1] - v["mean_angular_value_f1"]) < 1e-6 and abs(m[3] - v["mean_distance_of_true_pairs"]) < 1e-6
+    assert abs(m[2] - M.mean_angular_value(f2)) < 1e-6
 
 
 def test_runner_end_to_end(gpu, tmp_path, monkeypatch):
@@ -148,3 +155,44 @@ def test_runner_end_to_end(gpu, tmp_path, monkeypatch):
     m.load_state_dict(torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True))
     sd = torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True)
     assert torch.equal(m.param("visual.proj").cpu(), sd["module.visual.proj"])
+
+
+def test_full_state_sidecar_resume_is_bit_exact(gpu, tmp_path, monkeypatch):
+    """Opt-in sidecar next to the reference-format checkpoint (weights only, :983): 4 epochs in one go == 2 epochs, then a resume from
+    models/<run>_epoch_2.pt + .state.pt for 2 more (same losses, bit-identical final weights); without the sidecar the resume restores
+    the weights only, as the reference does (:719-724)."""
+    from sparsify_clip_amd import train as T
+    from sparsify_clip_amd.config import finalize_config
+    monkeypatch.chdir(tmp_path)
+    base = {"project_name": "t", "run_name": "sc", "seed": 1, "learning_rate": 1e-3, "batch_size": 8, "model": "tiny", "num_train_samples": 24,
+            "num_test_samples": 16, "epochs": 4, "loss_type": "anchor", "only_lunif_epochs": 0, "anchor_temperature": 0.1,
+            "anchor_temperature_learnable": True, "save_checkpoint_every_n_epochs": 2, "resume_checkpoint": False, "fp16": False,
+            "full_state_checkpoint": True}
+
+    def run(cfg_over, log):
+        cfg = finalize_config(dict(base, **cfg_over), 0, {"precision": "fp32"})
+        logger = T.JsonlLogger(None)
+        tr_l, te_l = T.dataset_loader(cfg, gpu)
+        model = T.train_model(cfg, tr_l, te_l, gpu, logger)
+        log.extend(r["train_loss"] for r in logger.rows if "train_loss" in r)
+        return model.flat.clone()
+
+    full_losses, a_losses, b_losses = [], [], []
+    w_full = run({}, full_losses)
+    sd2 = torch.load("models/sc_epoch_2.pt", map_location="cpu", weights_only=True)
+    st2 = torch.load("models/sc_epoch_2.state.pt", map_location="cpu", weights_only=True)
+    assert set(st2) >= {"adam_m", "adam_v", "counters", "weights", "temperature"} and st2["counters"].tolist()[1:3] == [6, 1]
+    # the 4-epoch run's LR schedule spans 12 steps: resume with the same total so the schedule continues (epochs = 2 more of 4)
+    T.os.rename("models/sc_epoch_2.pt", "models/keep.pt"), T.os.rename("models/sc_epoch_2.state.pt", "models/keep.state.pt")
+    cfg_resume = {"resume_checkpoint": "models/keep.pt", "epochs": 2, "run_name": "sc2"}
+    real_trainer = T.Trainer
+
+    class ResumeTrainer(real_trainer):      # same t_total as the uninterrupted run (the reference derives it from config["epochs"])
+        def __init__(self, config, device, steps_per_epoch, logger=None, model=None):
+            super().__init__(dict(config, epochs=4), device, steps_per_epoch, logger, model)
+
+    monkeypatch.setattr(T, "Trainer", ResumeTrainer)
+    w_resumed = run(cfg_resume, b_losses)
+    assert b_losses == full_losses[6:], (b_losses, full_losses)
+    assert torch.equal(w_resumed, w_full)
+    assert sd2.keys() == torch.load("models/sc2_epoch_4.pt", map_location="cpu", weights_only=True).keys()
