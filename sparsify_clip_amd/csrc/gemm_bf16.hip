@@ -47,6 +47,7 @@ struct GemmBf16Params {
     float* cs_partial;         // TN: [splits][M] partial column sums when the contraction is split
     float cs_beta;
     int group_m, group_n;      // NT 256x256: tile-walk cell (row tiles x column tiles an XCD's workgroups cover at a time)
+    int half_tiles, half_m0;      // persistent NT kernel: 128x256 tiles that follow the 256x256 ones, covering rows half_m0 .. M - 1
     unsigned long long* stamps;   // diagnostic builds of the persistent NT kernel only (sc_gemm_bf16_nt_stamps): [tile][4] s_memtime values
     EpiParams epi;
 };
@@ -398,7 +399,8 @@ __device__ __forceinline__ void ntb_read(bf16x8& dst, unsigned base) {
 // I < 4, of its B fragment I into the other B set.  The 12 reads of a sub-step are therefore issued in the order
 // a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7.  LATE (measured, no gain, not used): enter the sub-step with a4..a7 still in flight
 // (s_waitcnt lgkmcnt(4)); LDS reads return in order, so before group I >= 4 "at most 11 outstanding" proves a[I] has landed.
-template <int I, bool LOAD, bool LATE = false>
+// NG = row tiles of the wave (8: 128-row wave tile; 4: the 64-row wave tile of the persistent kernel's half tiles)
+template <int I, bool LOAD, bool LATE = false, int NG = 8>
 __device__ __forceinline__ void ntb_substep(bf16x8 (&a)[8], const bf16x8 (&b)[4], bf16x8 (&bn)[4], unsigned abase, unsigned bbase) {
     if constexpr (LATE && I >= 4) {
         if constexpr (LOAD) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
@@ -409,7 +411,7 @@ __device__ __forceinline__ void ntb_substep(bf16x8 (&a)[8], const bf16x8 (&b)[4]
         ntb_read<I * 2048>(a[I], abase);
         if constexpr (I < 4) ntb_read<I * 2048>(bn[I], bbase);
     }
-    if constexpr (I + 1 < 8) ntb_substep<I + 1, LOAD, LATE>(a, b, bn, abase, bbase);
+    if constexpr (I + 1 < NG) ntb_substep<I + 1, LOAD, LATE, NG>(a, b, bn, abase, bbase);
 }
 template <int N>
 __device__ __forceinline__ void ntb_zero() {
@@ -728,12 +730,12 @@ __device__ __forceinline__ void ntp_row_tile(const NtpEpi& c, int lane, const Nt
     }
 }
 
-template <int EPI, int I>
+template <int EPI, int I, int NP>
 __device__ __forceinline__ void ntp_epilogue_rows(const NtpEpi& c, int lane, const NtpAux<EPI>& cur, bool do_cs, f32x4& cs0, f32x4& cs1) {
     NtpAux<EPI> nxt;
-    if constexpr (I + 1 < 8 && (EPI == NTP_DGELU || EPI == NTP_RESID)) ntp_aux_load<EPI, I + 1>(nxt, c);
+    if constexpr (I + 1 < NP && (EPI == NTP_DGELU || EPI == NTP_RESID)) ntp_aux_load<EPI, I + 1>(nxt, c);
     ntp_row_tile<EPI, I>(c, lane, cur, do_cs, cs0, cs1);
-    if constexpr (I + 1 < 8) ntp_epilogue_rows<EPI, I + 1>(c, lane, nxt, do_cs, cs0, cs1);
+    if constexpr (I + 1 < NP) ntp_epilogue_rows<EPI, I + 1, NP>(c, lane, nxt, do_cs, cs0, cs1);
 }
 
 __device__ __forceinline__ unsigned long long ntp_stamp() {
@@ -742,17 +744,183 @@ __device__ __forceinline__ unsigned long long ntp_stamp() {
     return t;
 }
 
+struct NtpTile {   // one entry of a workgroup's tile list (wave-uniform; three ints, so that copies stay in SGPRs)
+    int m0, n0;
+    int half;        // != 0: 128 x 256 instead of 256 x 256
+};
+
+// Tiles 0 .. full-1 are 256x256 (band / cell walk of the one-tile-per-workgroup kernel), tiles full .. full+half_tiles-1 are
+// 128x256 and cover the rows from half_m0 on: the launcher turns the last, partly filled round of 256x256 tiles into (at most
+// one round of) half tiles, so that the tail of the launch costs half a tile time per CU instead of a whole one.
+__device__ __forceinline__ NtpTile ntp_tile_of(const GemmBf16Params& p, int vb, int full) {
+    NtpTile t;
+    if (vb < full) {
+        const int GM = p.group_m, GN = p.group_n;
+        const int tile = xcd_remap(vb, full);
+        const int band = tile / (GM * p.tiles_n), rb = tile - band * (GM * p.tiles_n);
+        const int rows = min(GM, p.tiles_m - band * GM);
+        const int cell = rb / (rows * GN), rc = rb - cell * (rows * GN);
+        const int gw = min(GN, p.tiles_n - cell * GN);
+        t.m0 = (band * GM + rc / gw) * B_M; t.n0 = (cell * GN + rc % gw) * B_N;
+        t.half = 0;
+    } else {
+        const int h = xcd_remap(vb - full, p.half_tiles);   // consecutive column tiles of one half row panel stay on one XCD
+        t.m0 = p.half_m0 + (h / p.tiles_n) * (B_M / 2); t.n0 = (h % p.tiles_n) * B_N;
+        t.half = 1;
+    }
+    return t;
+}
+
+// LDS-DMA of K-tile KT of tile `t` into stage S.  Full tile: wave w brings A rows 32 w .. 32 w + 31 (4 instructions) and the same B
+// rows; half tile: A rows 16 w .. 16 w + 15 (2 instructions, the per-lane offsets of a full tile against a base moved back by 16 w rows).
+__device__ __forceinline__ void ntp_stage(const GemmBf16Params& p, const NtpTile& t, int stage, int kt, unsigned lds0, int wave, const unsigned (&oa)[4],
+                                          const unsigned (&ob)[4]) {
+    const unsigned la = lds0 + stage * B_STAGE + (wave * 32) * 128;
+    const char* ak = (const char*)p.A + ((int64_t)t.m0 * p.lda + kt * KSTEP) * 2;
+    const char* bk = (const char*)p.B + ((int64_t)t.n0 * p.ldb + kt * KSTEP) * 2;
+    if (t.half) {
+        const char* akh = ak - (int64_t)(wave * 16) * p.lda * 2;
+        const unsigned lah = lds0 + stage * B_STAGE + (wave * 16) * 128;
+        glds16_saddr(akh, oa[0], lah);
+        glds16_saddr(akh, oa[1], lah + 1024);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16_saddr(ak, oa[q], la + q * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16_saddr(bk, ob[q], la + B_A + q * 1024);
+}
+
+// One tile: main loop on the stages requested earlier, request of the next tile's first two K-tiles between the two sub-steps of the
+// last K-tile, epilogue.  HALF: wave (wm, wn) owns rows 64 wm .. 64 wm + 63 (4 MFMA row tiles, accumulators a0 .. a63).
+template <int EPI, bool HALF, bool STAMP>
+__device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem, unsigned lds0, int lane, int wave, const NtpTile& cur, const NtpTile& nxt,
+                                             bool more, bool first, const unsigned (&oa)[4], const unsigned (&ob)[4], int vb) {
+    constexpr int NG = HALF ? 4 : 8;
+    constexpr bool OUT_F32 = EPI == NTP_RESID;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = p.K / KSTEP;
+    bf16x8 a[8], b0[4], b1[4];
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned pos0 = ((fq) ^ (lane & 7)) * 16, pos1 = ((4 + fq) ^ (lane & 7)) * 16;
+    const unsigned fa = lds0 + (wm * (HALF ? 64 : 128) + frow) * 128, fb = lds0 + B_A + (wn * 64 + frow) * 128;
+    const unsigned fa00 = fa + pos0, fa01 = fa + pos1, fa10 = fa + B_STAGE + pos0, fa11 = fa + B_STAGE + pos1;
+    const unsigned fb00 = fb + pos0, fb01 = fb + pos1, fb10 = fb + B_STAGE + pos0, fb11 = fb + B_STAGE + pos1;
+#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0)   /* K-tile KT is not the last one: as NTB_FULL */    \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        ntb_substep<0, true, false, NG>(a, b0, b1, A_S1, B_S1);                                       \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if ((KT) + 2 < nk) ntp_stage(p, cur, S, (KT) + 2, lds0, wave, oa, ob);                    \
+        ntb_substep<0, true, false, NG>(a, b1, b0, A_N0, B_N0);                                       \
+    } while (0)
+    ntb_zero<0>();
+    // K-tile 0 of this tile: requested in the prologue (first tile: K-tile 1 is the youngest request and may stay in flight)
+    // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    if constexpr (STAMP) ts0 = ntp_stamp();
+    if (first && nk > 1 && !HALF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (STAMP) ts1 = ntp_stamp();
+    // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 [a4 a5 a6 a7]): the loop's waits rely on it
+    ntb_read<0>(a[0], fa00); ntb_read<0>(b0[0], fb00); ntb_read<2048>(a[1], fa00); ntb_read<2048>(b0[1], fb00);
+    ntb_read<4096>(a[2], fa00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(a[3], fa00); ntb_read<6144>(b0[3], fb00);
+    if constexpr (!HALF) {
+        ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
+    }
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
+        NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00);
+    }
+    const bool two_left = kt + 1 < nk;
+    if (two_left) NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
+    // last K-tile: sub-step 0 under the reads of sub-step 1; then every read of both stages has retired on every wave (barrier),
+    // so the next tile's first two K-tiles are requested here, under the last MFMAs and the epilogue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ntb_substep<0, true, false, NG>(a, b0, b1, two_left ? fa11 : fa01, two_left ? fb11 : fb01);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (more) {
+        ntp_stage(p, nxt, 0, 0, lds0, wave, oa, ob);
+        if (nk > 1) ntp_stage(p, nxt, 1, 1, lds0, wave, oa, ob);
+    }
+    ntb_substep<0, false, false, NG>(a, b1, b0, 0u, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
+#undef NTP_FULL
+    if constexpr (STAMP) ts2 = ntp_stamp();
+
+    // ---- epilogue of the tile
+    {
+        const EpiParams& e = p.epi;
+        const int erow = lane >> 3, ecol = (lane & 7) * 8;
+        const int mw = cur.m0 + wm * (HALF ? 64 : 128), nw = cur.n0 + wn * 64;
+        NtpEpi c;
+        constexpr int ES = OUT_F32 ? 4 : 2;
+        c.row_bytes_c = (unsigned)(p.ldc * ES);
+        c.c = (char*)p.C + ((int64_t)mw * p.ldc + nw) * ES;
+        c.voff_c = (unsigned)((erow * (int)p.ldc + ecol) * ES);
+        c.aux = nullptr; c.pre = nullptr; c.row_bytes_aux = c.row_bytes_pre = 0; c.voff_aux = c.voff_pre = 0;
+        if constexpr (EPI == NTP_DGELU) {
+            c.row_bytes_aux = (unsigned)(e.ld_aux * 2);
+            c.aux = (const char*)e.dgelu_pre + ((int64_t)mw * e.ld_aux + nw) * 2;
+            c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
+        }
+        if constexpr (EPI == NTP_RESID) {
+            c.row_bytes_aux = (unsigned)(e.ld_aux * 4);
+            c.aux = (const char*)e.resid + ((int64_t)mw * e.ld_aux + nw) * 4;
+            c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 4);
+        }
+        if constexpr (EPI == NTP_GELU_PRE) {
+            c.row_bytes_pre = (unsigned)(e.ld_aux * 2);
+            c.pre = (char*)e.pre_out + ((int64_t)mw * e.ld_aux + nw) * 2;
+            c.voff_pre = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
+        }
+        c.slab = smem + 2 * B_STAGE + wave * P_SLAB;
+        c.slab_wr = smem + 2 * B_STAGE + wave * P_SLAB + frow * 256;
+        c.bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; c.bias1 = c.bias0;
+        if (e.bias) { c.bias0 = *(const f32x4*)(e.bias + nw + ecol); c.bias1 = *(const f32x4*)(e.bias + nw + ecol + 4); }
+        const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;
+        f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+        NtpAux<EPI> x0;
+        if constexpr (EPI == NTP_DGELU || EPI == NTP_RESID) ntp_aux_load<EPI, 0>(x0, c);
+        ntp_epilogue_rows<EPI, 0, NG>(c, lane, x0, do_cs, cs0, cs1);
+        if constexpr (EPI == NTP_DGELU) {
+            if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per 64-row slice of the output
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs0[j] += __shfl_xor(cs0[j], 8, 64);  cs1[j] += __shfl_xor(cs1[j], 8, 64);
+                    cs0[j] += __shfl_xor(cs0[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64);
+                    cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
+                }
+                if (lane < 8) {   // partial rows: one per 128 output rows for full tiles, one per 64 rows for half tiles (the rows after them)
+                    const int64_t slot = HALF ? (int64_t)(p.half_m0 / 128) + (mw - p.half_m0) / 64 : (int64_t)(mw / 128);
+                    float* dst = e.cs_partial + slot * p.N + nw + ecol;
+                    *(f32x4*)dst = cs0;
+                    *(f32x4*)(dst + 4) = cs1;
+                }
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        ts3 = ntp_stamp();
+        if (threadIdx.x == 0 && p.stamps) {
+            unsigned long long* d = p.stamps + (size_t)vb * 4;
+            d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3;
+        }
+    }
+}
+
 // STAMP = true is a DIAGNOSTIC instance (tools/gemm_stamps.py): wave 0 records s_memtime at the start of a tile's main loop, at its
 // end, and at the end of the epilogue into p.stamps (a buffer nothing else reads); the production instances contain no stamp.
 template <int EPI, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Params p) {
     __shared__ __attribute__((aligned(1024))) char smem[P_LDS];
-    constexpr bool OUT_F32 = EPI == NTP_RESID;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int GM = p.group_m, GN = p.group_n;
+    const int full = p.tiles_m * p.tiles_n, ntiles = full + p.half_tiles;
     const int nk = p.K / KSTEP;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
 
@@ -768,152 +936,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
             ob[q] = (unsigned)(((wave * 32 + q * 8 + srow) * p.ldb + schunk * 8) * 2);
         }
     }
-    const char* a_tile;
-    const char* b_tile;
-    // virtual block id -> tile origin (the band / cell walk of the one-tile-per-workgroup kernel)
-#define NTP_TILE(VB, M0, N0)                                                                          \
-    do {                                                                                              \
-        const int tile__ = xcd_remap((VB), ntiles);                                                   \
-        const int band__ = tile__ / (GM * p.tiles_n), rb__ = tile__ - band__ * (GM * p.tiles_n);      \
-        const int rows__ = min(GM, p.tiles_m - band__ * GM);                                          \
-        const int cell__ = rb__ / (rows__ * GN), rc__ = rb__ - cell__ * (rows__ * GN);                \
-        const int gw__ = min(GN, p.tiles_n - cell__ * GN);                                            \
-        (M0) = (band__ * GM + rc__ / gw__) * B_M; (N0) = (cell__ * GN + rc__ % gw__) * B_N;           \
-        a_tile = (const char*)p.A + (int64_t)(M0) * p.lda * 2;                                        \
-        b_tile = (const char*)p.B + (int64_t)(N0) * p.ldb * 2;                                        \
-    } while (0)
-#define NTP_STAGE(S, KT)                                                                              \
-    do {                                                                                              \
-        const unsigned la__ = lds0 + (S) * B_STAGE + (wave * 32) * 128;                               \
-        const char* ak__ = a_tile + (KT) * (KSTEP * 2);                                               \
-        const char* bk__ = b_tile + (KT) * (KSTEP * 2);                                               \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16_saddr(ak__, oa[q], la__ + q * 1024);     \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16_saddr(bk__, ob[q], la__ + B_A + q * 1024); \
-    } while (0)
-#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0)   /* tile KT is not the last one: as NTB_FULL */      \
-    do {                                                                                              \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
-        ntb_substep<0, true>(a, b0, b1, A_S1, B_S1);                                                  \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
-        __builtin_amdgcn_s_barrier();                                                                 \
-        if ((KT) + 2 < nk) NTP_STAGE(S, (KT) + 2);                                                    \
-        ntb_substep<0, true>(a, b1, b0, A_N0, B_N0);                                                  \
-    } while (0)
-
-    int vb = blockIdx.x, m0, n0;
-    NTP_TILE(vb, m0, n0);
-    NTP_STAGE(0, 0);
-    if (nk > 1) NTP_STAGE(1, 1);
+    int vb = blockIdx.x;
+    NtpTile cur = ntp_tile_of(p, vb, full);
+    ntp_stage(p, cur, 0, 0, lds0, wave, oa, ob);
+    if (nk > 1) ntp_stage(p, cur, 1, 1, lds0, wave, oa, ob);
     bool first = true;
     for (;;) {
-        bf16x8 a[8], b0[4], b1[4];
-        const int frow = lane & 15, fq = lane >> 4;
-        const unsigned pos0 = ((fq) ^ (lane & 7)) * 16, pos1 = ((4 + fq) ^ (lane & 7)) * 16;
-        const unsigned fa = lds0 + (wm * 128 + frow) * 128, fb = lds0 + B_A + (wn * 64 + frow) * 128;
-        const unsigned fa00 = fa + pos0, fa01 = fa + pos1, fa10 = fa + B_STAGE + pos0, fa11 = fa + B_STAGE + pos1;
-        const unsigned fb00 = fb + pos0, fb01 = fb + pos1, fb10 = fb + B_STAGE + pos0, fb11 = fb + B_STAGE + pos1;
-        ntb_zero<0>();
-        // K-tile 0 of this tile: requested in the prologue (first tile: K-tile 1 is the youngest request and may stay in flight)
-        // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
-        if (first && nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-        if constexpr (STAMP) ts0 = ntp_stamp();
-        first = false;
-        __builtin_amdgcn_s_barrier();
-        if constexpr (STAMP) ts1 = ntp_stamp();
-        // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7): the loop's counted waits rely on it
-        ntb_read<0>(a[0], fa00); ntb_read<0>(b0[0], fb00); ntb_read<2048>(a[1], fa00); ntb_read<2048>(b0[1], fb00);
-        ntb_read<4096>(a[2], fa00); ntb_read<4096>(b0[2], fb00); ntb_read<6144>(a[3], fa00); ntb_read<6144>(b0[3], fb00);
-        ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
-        int kt = 0;
-        for (; kt + 2 < nk; kt += 2) {
-            NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
-            NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00);
-        }
-        const bool two_left = kt + 1 < nk;
-        if (two_left) NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
-        // last K-tile: sub-step 0 under the reads of sub-step 1; then every read of both stages has retired on every wave (barrier),
-        // so the next tile's first two K-tiles are requested here, under the last 32 MFMAs and the epilogue
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ntb_substep<0, true>(a, b0, b1, two_left ? fa11 : fa01, two_left ? fb11 : fb01);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int em0 = m0, en0 = n0;
-        vb += gridDim.x;
-        const bool more = vb < ntiles;
-        if (more) {
-            NTP_TILE(vb, m0, n0);
-            NTP_STAGE(0, 0);
-            if (nk > 1) NTP_STAGE(1, 1);
-        }
-        ntb_substep<0, false>(a, b1, b0, 0u, 0u);
-        asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
-        if constexpr (STAMP) ts2 = ntp_stamp();
-
-        // ---- epilogue of tile (em0, en0)
-        {
-            const EpiParams& e = p.epi;
-            const int erow = lane >> 3, ecol = (lane & 7) * 8;
-            const int mw = em0 + wm * 128, nw = en0 + wn * 64;
-            NtpEpi c;
-            constexpr int ES = OUT_F32 ? 4 : 2;
-            c.row_bytes_c = (unsigned)(p.ldc * ES);
-            c.c = (char*)p.C + ((int64_t)mw * p.ldc + nw) * ES;
-            c.voff_c = (unsigned)((erow * (int)p.ldc + ecol) * ES);
-            c.aux = nullptr; c.pre = nullptr; c.row_bytes_aux = c.row_bytes_pre = 0; c.voff_aux = c.voff_pre = 0;
-            if constexpr (EPI == NTP_DGELU) {
-                c.row_bytes_aux = (unsigned)(e.ld_aux * 2);
-                c.aux = (const char*)e.dgelu_pre + ((int64_t)mw * e.ld_aux + nw) * 2;
-                c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
-            }
-            if constexpr (EPI == NTP_RESID) {
-                c.row_bytes_aux = (unsigned)(e.ld_aux * 4);
-                c.aux = (const char*)e.resid + ((int64_t)mw * e.ld_aux + nw) * 4;
-                c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 4);
-            }
-            if constexpr (EPI == NTP_GELU_PRE) {
-                c.row_bytes_pre = (unsigned)(e.ld_aux * 2);
-                c.pre = (char*)e.pre_out + ((int64_t)mw * e.ld_aux + nw) * 2;
-                c.voff_pre = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
-            }
-            c.slab = smem + 2 * B_STAGE + wave * P_SLAB;
-            c.slab_wr = smem + 2 * B_STAGE + wave * P_SLAB + frow * 256;
-            c.bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; c.bias1 = c.bias0;
-            if (e.bias) { c.bias0 = *(const f32x4*)(e.bias + nw + ecol); c.bias1 = *(const f32x4*)(e.bias + nw + ecol + 4); }
-            const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;
-            f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
-            NtpAux<EPI> x0;
-            if constexpr (EPI == NTP_DGELU || EPI == NTP_RESID) ntp_aux_load<EPI, 0>(x0, c);
-            ntp_epilogue_rows<EPI, 0>(c, lane, x0, do_cs, cs0, cs1);
-            if constexpr (EPI == NTP_DGELU) {
-                if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per (row tile, wave row)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        cs0[j] += __shfl_xor(cs0[j], 8, 64);  cs1[j] += __shfl_xor(cs1[j], 8, 64);
-                        cs0[j] += __shfl_xor(cs0[j], 16, 64); cs1[j] += __shfl_xor(cs1[j], 16, 64);
-                        cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
-                    }
-                    if (lane < 8) {
-                        float* dst = e.cs_partial + (int64_t)((em0 / B_M) * 2 + wm) * p.N + nw + ecol;
-                        *(f32x4*)dst = cs0;
-                        *(f32x4*)(dst + 4) = cs1;
-                    }
-                }
-            }
-        }
-        if constexpr (STAMP) {
-            ts3 = ntp_stamp();
-            if (t == 0 && p.stamps) {
-                unsigned long long* d = p.stamps + (size_t)(vb - gridDim.x) * 4;
-                d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3;
-            }
-        }
+        const int vn = vb + gridDim.x;
+        const bool more = vn < ntiles;
+        NtpTile nxt = cur;
+        if (more) nxt = ntp_tile_of(p, vn, full);
+        if (cur.half) ntp_run_tile<EPI, true, STAMP>(p, smem, lds0, lane, wave, cur, nxt, more, first, oa, ob, vb);
+        else ntp_run_tile<EPI, false, STAMP>(p, smem, lds0, lane, wave, cur, nxt, more, first, oa, ob, vb);
         if (!more) break;
+        first = false;
+        cur = nxt;
+        vb = vn;
     }
-#undef NTP_FULL
-#undef NTP_STAGE
-#undef NTP_TILE
 }
 
 // ------------------------------------------------------------------------------------------------ TN
@@ -1355,6 +1394,74 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
             static const int g_m = [] { const char* e = getenv("SC_GEMM_NT_GROUP_M"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_M; }();   // A/B knobs
             static const int g_n = [] { const char* e = getenv("SC_GEMM_NT_GROUP_N"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_N; }();
             p.group_m = g_m; p.group_n = g_n;
+            p.half_tiles = 0; p.half_m0 = 0;
+            // persistent kernel: whole tiles and one of the step's four epilogues; SC_GEMM_NT=b forces one tile per workgroup (A/B)
+            static const bool one_tile_wg = [] { const char* e = getenv("SC_GEMM_NT"); return e && e[0] == 'b'; }();
+            const EpiParams& pe = p.epi;
+            int kind = -1;
+            const bool aux_ok = epi.ld_aux == ldc && epi.ld_aux < (1 << 22);
+            const bool cs_room = epi.colsum && epi.colsum_ws_bytes >= (size_t)(m / 64 + 2) * n * sizeof(float) && sc_aligned(epi.colsum_ws, 16);
+            if (!one_tile_wg && pe.alpha == 1.f && pe.beta == 0.f && m % (B_M / 2) == 0 && n % B_N == 0 && lda < (1 << 22) && ldb < (1 << 22) && ldc < (1 << 22)) {
+                if (out_dtype == SC_F32) {
+                    if (pe.resid && pe.resid_dtype == SC_F32 && !pe.pre_out && pe.act == 0 && !pe.dgelu_pre && !epi.colsum && aux_ok) kind = NTP_RESID;
+                } else if (pe.pre_out && pe.act == 1 && !pe.resid && !pe.dgelu_pre && !epi.colsum && aux_ok) kind = NTP_GELU_PRE;
+                else if (pe.dgelu_pre && !pe.pre_out && pe.act == 0 && !pe.resid && aux_ok && (!epi.colsum || cs_room)) kind = NTP_DGELU;
+                else if (!pe.dgelu_pre && !pe.pre_out && pe.act == 0 && !pe.resid && !epi.colsum) kind = NTP_BIAS;
+            }
+            if (kind >= 0) {
+                // One workgroup per CU walks the tile list: `full` 256x256 tiles, then half tiles (128x256) over the remaining rows.
+                // Tile-count quantisation: with 600 tiles on 256 CUs (N = 768) a third round of whole tiles would run 88 workgroups
+                // while 168 CUs idle; turning the rows of that partial round into 176 half tiles costs every CU at most half a
+                // tile time (+10 %: same prologue / epilogue overheads on half the MFMA work).  The split is chosen by evaluating
+                // the most loaded workgroup's cost for "all whole tiles" and for "whole rounds + half tiles".
+                const int G = sc_num_cus();
+                const int64_t tm_all = m / B_M, tail = (m % B_M) / (B_M / 2);        // tail = 1: a last 128-row panel
+                auto cost = [&](int64_t full_tiles, int64_t half_tiles) {
+                    double worst = 0.0;
+                    const int64_t total = full_tiles + half_tiles;
+                    for (int b = 0; b < G && b < total; ++b) {
+                        const int64_t mine = (total - b + G - 1) / G;
+                        const int64_t mine_full = full_tiles > b ? (full_tiles - b + G - 1) / G : 0;
+                        const double c = (double)mine_full + 0.55 * (double)(mine - mine_full);
+                        worst = c > worst ? c : worst;
+                    }
+                    return worst;
+                };
+                int64_t tm_main = tm_all;
+                {
+                    const int64_t rounds = (tm_all * tn_b) / G;
+                    const int64_t tm_b2 = (rounds * G) / tn_b;      // row tiles that fill whole rounds
+                    static const bool split_on2 = [] { const char* e = getenv("SC_GEMM_NT_SPLIT"); return !(e && e[0] == '0'); }();
+                    if (split_on2 && tm_b2 < tm_all &&
+                        cost(tm_b2 * tn_b, ((tm_all - tm_b2) * 2 + tail) * tn_b) + 0.02 < cost(tm_all * tn_b, tail * tn_b))
+                        tm_main = tm_b2;
+                }
+                p.M = (int)m;
+                p.tiles_m = (int)tm_main; p.tiles_n = (int)tn_b;
+                p.half_m0 = (int)(tm_main * B_M);
+                p.half_tiles = (int)(((m - tm_main * B_M) / (B_M / 2)) * tn_b);
+                const int64_t total = (int64_t)p.tiles_m * p.tiles_n + p.half_tiles;
+                int64_t cs_slabs = 0;
+                if (epi.colsum) {   // partial rows: one per 128 output rows of the whole tiles, one per 64 rows of the half tiles; every slot is written
+                    p.epi.cs_partial = (float*)epi.colsum_ws;
+                    cs_slabs = tm_main * 2 + (m - tm_main * B_M) / 64;
+                    cs_fused = true;
+                }
+                const unsigned gridp = (unsigned)(total < G ? total : G);
+                if (p.stamps) {   // diagnostic instances
+                    if (kind == NTP_RESID) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_RESID, true>), dim3(gridp), dim3(512), 0, stream, p);
+                    else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_GELU_PRE, true>), dim3(gridp), dim3(512), 0, stream, p);
+                    else if (kind == NTP_DGELU) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_DGELU, true>), dim3(gridp), dim3(512), 0, stream, p);
+                    else hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_BIAS, true>), dim3(gridp), dim3(512), 0, stream, p);
+                } else if (kind == NTP_RESID) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_RESID>, dim3(gridp), dim3(512), 0, stream, p);
+                else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_GELU_PRE>, dim3(gridp), dim3(512), 0, stream, p);
+                else if (kind == NTP_DGELU) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_DGELU>, dim3(gridp), dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_BIAS>, dim3(gridp), dim3(512), 0, stream, p);
+                SC_CHECK_LAUNCH();
+                if (epi.colsum) return sc_colsum_reduce((const float*)epi.colsum_ws, (int)cs_slabs, n, epi.colsum, epi.colsum_accumulate, stream);
+                return SC_OK;
+            }
+            // general shapes / epilogues: one 256x256 tile per workgroup, the rows of a partly filled round on the 256x128 kernel
             p.M = (int)m_main;
             p.tiles_m = (int)sc_cdiv(m_main, B_M); p.tiles_n = (int)tn_b;
             const unsigned gridb = (unsigned)(p.tiles_m * p.tiles_n);
@@ -1362,34 +1469,8 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                 p.epi.cs_partial = (float*)epi.colsum_ws;   // [2 * tiles_m][N]; rows past M contribute nothing, every slot is written
                 cs_fused = true;
             }
-            // persistent kernel: whole tiles and one of the step's four epilogues; SC_GEMM_NT=b forces one tile per workgroup (A/B)
-            static const bool one_tile_wg = [] { const char* e = getenv("SC_GEMM_NT"); return e && e[0] == 'b'; }();
-            const EpiParams& pe = p.epi;
-            int kind = -1;
-            const bool aux_ok = epi.ld_aux == ldc && epi.ld_aux < (1 << 22);
-            if (pe.alpha == 1.f && pe.beta == 0.f && m_main % B_M == 0 && n % B_N == 0 && lda < (1 << 22) && ldb < (1 << 22) && ldc < (1 << 22)) {
-                if (out_dtype == SC_F32) {
-                    if (pe.resid && pe.resid_dtype == SC_F32 && !pe.pre_out && pe.act == 0 && !pe.dgelu_pre && !epi.colsum && aux_ok) kind = NTP_RESID;
-                } else if (pe.pre_out && pe.act == 1 && !pe.resid && !pe.dgelu_pre && !epi.colsum && aux_ok) kind = NTP_GELU_PRE;
-                else if (pe.dgelu_pre && !pe.pre_out && pe.act == 0 && !pe.resid && aux_ok && (!epi.colsum || cs_fused)) kind = NTP_DGELU;
-                else if (!pe.dgelu_pre && !pe.pre_out && pe.act == 0 && !pe.resid && !epi.colsum) kind = NTP_BIAS;
-            }
-            if (one_tile_wg || kind < 0) {
-                if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
-                else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
-            } else {   // one workgroup per CU walks the tile list
-                const unsigned gridp = gridb < (unsigned)sc_num_cus() ? gridb : (unsigned)sc_num_cus();
-                if (p.stamps) {   // diagnostic instances
-                    if (kind == NTP_RESID) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_RESID, true>), dim3(gridp), dim3(512), 0, stream, p);
-                    else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_GELU_PRE, true>), dim3(gridp), dim3(512), 0, stream, p);
-                    else if (kind == NTP_DGELU) hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_DGELU, true>), dim3(gridp), dim3(512), 0, stream, p);
-                    else hipLaunchKernelGGL((gemm_bf16_nt_pers_kernel<NTP_BIAS, true>), dim3(gridp), dim3(512), 0, stream, p);
-                } else
-                if (kind == NTP_RESID) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_RESID>, dim3(gridp), dim3(512), 0, stream, p);
-                else if (kind == NTP_GELU_PRE) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_GELU_PRE>, dim3(gridp), dim3(512), 0, stream, p);
-                else if (kind == NTP_DGELU) hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_DGELU>, dim3(gridp), dim3(512), 0, stream, p);
-                else hipLaunchKernelGGL(gemm_bf16_nt_pers_kernel<NTP_BIAS>, dim3(gridp), dim3(512), 0, stream, p);
-            }
+            if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<true>, dim3(gridb), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL(gemm_bf16_nt_big_kernel<false>, dim3(gridb), dim3(512), 0, stream, p);
             cs_rows_done = m_main;
             if (m_main < m) {   // the remaining rows: same operands and epilogue, pointers advanced by m_main rows
                 GemmBf16Params q = p;

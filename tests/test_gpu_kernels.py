@@ -90,12 +90,12 @@ def test_gemm_bf16_nt(ops, m, n, k, out_dtype):
 
 
 @pytest.mark.parametrize("m,n,k", [(4096, 1536, 64), (4100, 1544, 192), (4352, 2304, 768), (5000, 1800, 128), (10300, 2056, 128), (33000, 520, 64),
-                                   (32768, 1024, 192), (49152, 768, 64), (16384, 512, 128)])
+                                   (32768, 1024, 192), (49152, 768, 64), (16384, 512, 128), (8320, 768, 128)])
 def test_gemm_bf16_nt_wide(ops, m, n, k):
     """Shapes that dispatch to the 256x256 AGPR kernels (M >= 4096, N >= 512): full and ragged tiles, odd / even K-tile counts, the
     4th-6th with more than 256 tiles so that the leftover rows go to a second launch of the 256x128 kernel; the whole-tile shapes
-    run the PERSISTENT kernel for the step's four epilogues (1, 2 and 2-or-1 tiles per workgroup: 512 tiles, 510 of 576 tiles, 128
-    tiles) and the one-tile-per-workgroup kernel for the rest; every epilogue, checked element by element against fp64 on the same
+    run the PERSISTENT kernel for the step's four epilogues (512 whole tiles = 2 per workgroup; 510 whole + 132 half tiles; 256 half
+    tiles only; 96 whole tiles + a last 128-row panel of 3 half tiles) and the one-tile-per-workgroup kernel for the rest; every epilogue, checked element by element against fp64 on the same
     bf16 operands (computed on the device)."""
     a, w = rnd(m, k, seed=21, dtype=torch.bfloat16).to(DEV), rnd(n, k, seed=22, scale=0.1, dtype=torch.bfloat16).to(DEV)
     bias, resid = rnd(n, seed=23).to(DEV), rnd(m, n, seed=24).to(DEV)
