@@ -5,8 +5,7 @@ flight between an inline `ds_read*` and the hand-placed `s_waitcnt lgkmcnt(0)`. 
 fails the build if, inside one of those kernels,
   * the compiler itself touches an AGPR (v_accvgpr_write with a register source, v_accvgpr_mov) - it would be using the
     accumulators as spill space - or the kernel needs scratch;
-  * any instruction other than an MFMA or another LDS read names a VGPR that is the destination of an LDS read still in flight;
-  * (persistent NT kernel) any compiler-scheduled instruction names v127, the register its L2 "touch" loads land in at any time.
+  * any instruction other than an MFMA or another LDS read names a VGPR that is the destination of an LDS read still in flight.
 """
 from __future__ import annotations
 
@@ -92,8 +91,6 @@ def audit(asm_text: str):
                     problems.append(f"{name}: scratch access `{text}`")
                 if not in_asm and op.startswith("v_accvgpr") and report:
                     problems.append(f"{name}: compiler-generated AGPR traffic `{text}`")
-                if not in_asm and report and "nt_pers_kernel" in name and any(127 in _regs(x) for x in toks):
-                    problems.append(f"{name}: `{text}` names v127, the landing register of the L2 touches")
                 m = re.search(r"lgkmcnt\((\d+)\)", text) if op == "s_waitcnt" else None
                 if m:
                     n = int(m.group(1))

@@ -744,14 +744,6 @@ __device__ __forceinline__ unsigned long long ntp_stamp() {
     return t;
 }
 
-// L2 "touch": a 4-byte load per lane (one 128-byte line each) whose result is never used - it only pulls K-tiles that will be
-// LDS-DMA'd a few K-tiles later from HBM into the XCD's L2 (with 64 KiB of LDS-DMA in flight per CU an HBM-miss latency of ~2 us caps
-// the ingest at ~35 GB/s per CU; an L2 hit lands in a third of that).  The destination is v127, which the kernel reserves for this
-// purpose: no other instruction may name it (checked at build time, _asm_check.py), so a late-landing touch can corrupt nothing.
-__device__ __forceinline__ void ntp_touch(const char* line) {
-    asm volatile("global_load_dword v127, %0, off" : : "v"(line) : "v127", "memory");
-}
-
 struct NtpTile {   // one entry of a workgroup's tile list (wave-uniform; three ints, so that copies stay in SGPRs)
     int m0, n0;
     int half;        // != 0: 128 x 256 instead of 256 x 256
@@ -805,10 +797,6 @@ template <int EPI, bool HALF, bool STAMP>
 __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem, unsigned lds0, int lane, int wave, const NtpTile& cur, const NtpTile& nxt,
                                              bool more, bool first, const unsigned (&oa)[4], const unsigned (&ob)[4], int vb) {
     constexpr int NG = HALF ? 4 : 8;
-    // this lane's line of the tile's operand panels (lanes 0-31: A rows 32 w .. of the wave, lanes 32-63: B rows), K-tile 0
-    const int tl = lane & 31;
-    const char* touch_cur = lane < 32 ? (const char*)p.A + (int64_t)min(cur.m0 + wave * 32 + tl, p.M - 1) * p.lda * 2
-                                      : (const char*)p.B + (int64_t)(cur.n0 + wave * 32 + tl) * p.ldb * 2;
     constexpr bool OUT_F32 = EPI == NTP_RESID;
     const int wm = wave >> 2, wn = wave & 3;
     const int nk = p.K / KSTEP;
@@ -832,16 +820,8 @@ __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem
     // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     if constexpr (STAMP) ts0 = ntp_stamp();
-    // Later tiles: K-tile 0 was requested at the previous tile's last K-tile, BEFORE that tile's epilogue.  Requests retire in issue
-    // order, so "all but the youngest 16 (8 for a half tile)" covers K-tile 0 and 1 (at least 6 + 2 touches + 2 x 4 (8) epilogue
-    // stores were issued after K-tile 0's) while the last epilogue stores stay in flight under the first K-tile.
-    // (K = 64: no K-tile 1, nothing to count on: wait for everything.)
-    if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (first) {
-        if constexpr (HALF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // K-tile 1 (8 requests) and the two touches may stay in flight
-    } else if constexpr (HALF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (first && nk > 1 && !HALF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (STAMP) ts1 = ntp_stamp();
     // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 [a4 a5 a6 a7]): the loop's waits rely on it
@@ -866,10 +846,6 @@ __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem
     if (more) {
         ntp_stage(p, nxt, 0, 0, lds0, wave, oa, ob);
         if (nk > 1) ntp_stage(p, nxt, 1, 1, lds0, wave, oa, ob);
-        const char* touch_nxt = lane < 32 ? (const char*)p.A + (int64_t)min(nxt.m0 + wave * 32 + tl, p.M - 1) * p.lda * 2
-                                          : (const char*)p.B + (int64_t)(nxt.n0 + wave * 32 + tl) * p.ldb * 2;
-        ntp_touch(touch_nxt + min(2, nk - 1) * (KSTEP * 2));
-        ntp_touch(touch_nxt + min(3, nk - 1) * (KSTEP * 2));
     }
     ntb_substep<0, false, false, NG>(a, b1, b0, 0u, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs retire before the accumulators are read back
@@ -964,13 +940,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
     NtpTile cur = ntp_tile_of(p, vb, full);
     ntp_stage(p, cur, 0, 0, lds0, wave, oa, ob);
     if (nk > 1) ntp_stage(p, cur, 1, 1, lds0, wave, oa, ob);
-    {   // as at every later tile boundary: the two youngest requests are touches (K-tiles 2 and 3), the K loop's waits count on it
-        const int tl = lane & 31;
-        const char* touch0 = lane < 32 ? (const char*)p.A + (int64_t)min(cur.m0 + wave * 32 + tl, p.M - 1) * p.lda * 2
-                                       : (const char*)p.B + (int64_t)(cur.n0 + wave * 32 + tl) * p.ldb * 2;
-        ntp_touch(touch0 + min(2, nk - 1) * (KSTEP * 2));
-        ntp_touch(touch0 + min(3, nk - 1) * (KSTEP * 2));
-    }
     bool first = true;
     for (;;) {
         const int vn = vb + gridDim.x;
