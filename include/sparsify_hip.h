@@ -90,6 +90,15 @@ int sc_gemm_bf16_tn_colsum(int64_t m, int64_t n, int64_t r, const void* a, int64
                            float* c, int64_t ldc, float alpha, float beta, float* colsum_a, float colsum_beta,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* Up to four TN problems with ONE contraction length r (r % 64 == 0) in one launch: C_k = alpha * A_k^T B_k + beta * C_k.  The four
+ * weight gradients of a transformer block (same rows, different dY / X: autograd of the four nn.Linear under reference
+ * sparsify_clip.py:965) share the chip, so the contraction is split 2-5 ways (one set of partial slabs in ws, one fixed-order reduce)
+ * instead of 7-28 ways per problem.  All pointer arrays are HOST arrays of nprob entries. */
+size_t sc_gemm_bf16_tn_group_workspace_bytes(int nprob, const int64_t* m, const int64_t* n, int64_t r);
+int sc_gemm_bf16_tn_group(int nprob, const int64_t* m, const int64_t* n, int64_t r, const void* const* a, const int64_t* lda,
+                          const void* const* b, const int64_t* ldb, float* const* c, const int64_t* ldc, float alpha, float beta,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Loss head on [B,E] fp32 embeddings  (sparsify_clip.py:110-187, :334-355, :772-773, :804)
  * All *_fwd_bwd calls write the scalar loss to loss_out[0] (device) and the gradient of
@@ -194,6 +203,11 @@ int sc_pool_scatter(const float* d_out, const int32_t* idx, int64_t batch, int64
 int sc_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst(bf16) [cols,rows] = transpose(src fp32 [rows,cols]) */
 int sc_transpose_cast_bf16(const float* src, int64_t rows, int64_t cols, void* dst, void* stream);
+
+/* The same for a table of matrices in ONE launch (the ~100 [in,out] weight copies rebuilt after every optimiser step):
+ * table = DEVICE int64 [n_items][5] = {src pointer, dst pointer, rows, cols, first_block}, first_block = running sum of
+ * ceil(rows/32) * ceil(cols/32) over the preceding items (ascending), total_blocks = that sum over all items. */
+int sc_transpose_cast_bf16_batch(const int64_t* table, int64_t n_items, int64_t total_blocks, void* stream);
 
 /* One pre-LN residual attention block, forward and backward (K3-K8).  All pointers device. */
 typedef struct sc_block_desc {

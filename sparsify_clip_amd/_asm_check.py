@@ -12,7 +12,7 @@ from __future__ import annotations
 import re
 import subprocess
 
-KERNELS = ("gemm_bf16_nt_big_kernel", "gemm_bf16_nt_pers_kernel", "gemm_bf16_tn_big_kernel")
+KERNELS = ("gemm_bf16_nt_big_kernel", "gemm_bf16_nt_pers_kernel", "gemm_bf16_tn_big_kernel", "gemm_bf16_tn_group_kernel")
 
 
 def _regs(tok: str):

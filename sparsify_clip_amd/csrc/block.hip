@@ -16,6 +16,10 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
 int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
                            float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta);
 size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r);
+size_t sc_gemm_bf16_tn_group_ws(int nprob, const int64_t* m, const int64_t* n, int64_t r);
+int sc_gemm_bf16_tn_group_launch(int nprob, const int64_t* m, const int64_t* n, int64_t r, const void* const* a, const int64_t* lda, const void* const* b,
+                                 const int64_t* ldb, float* const* c, const int64_t* ldc, float alpha, float beta, void* ws, size_t ws_bytes,
+                                 hipStream_t stream);
 
 int sc_attention_f32_composed_fwd(const float* qkv, float* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, void* ws,
                                   size_t ws_bytes, hipStream_t st);
@@ -81,6 +85,11 @@ extern "C" size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t 
         const int64_t shapes[4][2] = {{3 * width, width}, {width, width}, {mlp_width, width}, {width, mlp_width}};
         for (auto& s : shapes) {
             const size_t w = sc_gemm_bf16_tn_ws(s[0], s[1], rows);
+            need = need > w ? need : w;
+        }
+        if (rows % 64 == 0) {   // the four weight gradients as one grouped launch
+            const int64_t gm[4] = {width, mlp_width, width, 3 * width}, gn[4] = {mlp_width, width, width, width};
+            const size_t w = sc_gemm_bf16_tn_group_ws(4, gm, gn, rows);
             need = need > w ? need : w;
         }
     }
@@ -172,8 +181,13 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     // MFMA units idle for its whole duration.
     static const bool gate_env = [] { const char* e = getenv("SC_BLOCK_DW_GATE"); return !(e && e[0] == '0'); }();
     const bool gate = two && gate_env;
+    // SC_BLOCK_DW_GROUP=0: four separate weight-gradient launches (A/B); default: ONE grouped launch per block, after the attention
+    // backward, when the bias gradients are taken elsewhere (fcs) and the rows are whole K-tiles
+    static const bool group_env = [] { const char* e = getenv("SC_BLOCK_DW_GROUP"); return !(e && e[0] == '0'); }();
+    const bool fcs_early = bf && [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();
+    const bool grouped = group_env && fcs_early && rows % 64 == 0;
     // ---- MLP half: c_proj, GELU', c_fc
-    if (!gate) {
+    if (!gate && !grouped) {
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
     }
@@ -190,7 +204,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     }
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
     if (ug) SC_TRY(sc_dgelu_mul_colsum_bf16(d->d_h, d->h_pre, rows, MLP, d->g_b_fc1, acc, d->ws, d->ws_bytes, st));
-    if (!gate) {
+    if (!gate && !grouped) {
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
         if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
@@ -203,12 +217,12 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
                             d->g_ln2_g, d->g_ln2_b, d->g_b_o, acc, d->ws, d->ws_bytes, stream));
     const void* gm = bf ? (const void*)d->d_res_t : (const void*)d->dx_mid;
     // ---- attention half: out_proj, attention, in_proj
-    if (!gate) {
+    if (!gate && !grouped) {
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
     }
     SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
-    if (gate) {   // everything the three GEMMs read (g, h_act, d_h, ln2_out, d_res_t, attn_out) is final here
+    if (gate && !grouped) {   // everything the three GEMMs read (g, h_act, d_h, ln2_out, d_res_t, attn_out) is final here
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
         SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
@@ -221,7 +235,15 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     else if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
     else SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
     SC_TRY(publish());
-    SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));
+    if (grouped) {   // dW of c_proj, c_fc, out_proj, in_proj: every operand (g, h_act, d_h, ln2_out, gm, attn_out, d_qkv, ln1_out) is final here
+        const int64_t pm[4] = {W, MLP, W, 3 * W}, pn[4] = {MLP, W, W, W};
+        const void* pa[4] = {g, d->d_h, gm, d->d_qkv};
+        const void* pb[4] = {d->h_act, d->ln2_out, d->attn_out, d->ln1_out};
+        float* pc[4] = {d->g_w_fc2, d->g_w_fc1, d->g_w_o, d->g_w_qkv};
+        SC_TRY(sc_gemm_bf16_tn_group_launch(4, pm, pn, rows, pa, pm, pb, pn, pc, pn, 1.f, acc ? 1.f : 0.f, wsw, wsw_bytes, ss));
+    } else {
+        SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));
+    }
     if (!fcs) SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
     // dx_in = dx_mid + LN1'(d_ln)

@@ -157,11 +157,42 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t
         for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
 }
 
+__device__ __forceinline__ int64_t sc_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 // dst[c][r] = bf16(src[r][c]) through a 32x33 LDS tile
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, int64_t rows, int64_t cols, bf16_t* dst) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < cols && r < rows) dst[c * rows + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
+    }
+}
+
+// the same for a whole table of matrices in ONE launch: item i = {src, dst, rows, cols, first_block}; block -> item by binary search
+__global__ __launch_bounds__(256) void transpose_cast_batch_kernel(const int64_t* table, int n_items) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n_items - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {   // last item whose first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 5 + 4] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* it = table + lo * 5;
+    const float* src = (const float*)it[0];
+    bf16_t* dst = (bf16_t*)it[1];
+    const int64_t rows = it[2], cols = it[3], local = b - it[4];
+    const int64_t bx = sc_cdiv_dev(cols, 32);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c0 = (local % bx) * 32, r0 = (local / bx) * 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
@@ -296,6 +327,13 @@ extern "C" int sc_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void*
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
+extern "C" int sc_transpose_cast_bf16_batch(const int64_t* table, int64_t n_items, int64_t total_blocks, void* stream) {
+    SC_REQUIRE(table && n_items > 0 && n_items < (1 << 20) && total_blocks > 0 && total_blocks < (1ll << 31), SC_ERR_ARG, "sc_transpose_cast_bf16_batch: bad argument");
+    hipLaunchKernelGGL(transpose_cast_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), table, (int)n_items);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
 extern "C" int sc_transpose_cast_bf16(const float* src, int64_t rows, int64_t cols, void* dst, void* stream) {
     SC_REQUIRE(src && dst && rows > 0 && cols > 0, SC_ERR_ARG, "sc_transpose_cast_bf16: bad argument");
     hipLaunchKernelGGL(transpose_cast_kernel, dim3((unsigned)sc_cdiv(cols, 32), (unsigned)sc_cdiv(rows, 32)), dim3(256), 0, ST(stream), src, rows, cols, (bf16_t*)dst);

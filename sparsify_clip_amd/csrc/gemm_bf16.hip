@@ -1178,13 +1178,12 @@ __device__ __forceinline__ void tnb_store(const GemmBf16Params& p, int split, in
     if constexpr (T + 1 < 32) tnb_store<T + 1>(p, split, mrow, ncol);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(GemmBf16Params p) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * TB_OPER];
+// the work of ONE workgroup: output tile `id % ntiles`, contraction slice `id / ntiles` of problem p
+__device__ __forceinline__ void tn_big_body(const GemmBf16Params& p, char* smem, int id) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int id = xcd_remap(blockIdx.x, ntiles * p.splits);
     const int split = id / ntiles, tile = id % ntiles;
     const int m0 = (tile / p.tiles_n) * B_M, n0 = (tile % p.tiles_n) * B_N;
     const int kt_begin = split * p.k_per_split;
@@ -1271,6 +1270,60 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(GemmBf16Params
 
     // D[n][m]: lane holds m = .. + (lane & 15), n = .. + 4 (lane >> 4) + reg
     tnb_store<0>(p, split, m0 + wm * 128 + i16, n0 + wn * 64 + 4 * g);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(GemmBf16Params p) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TB_OPER];
+    tn_big_body(p, smem, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits));
+}
+
+// Up to four weight-gradient problems with one contraction length (the four dW of a transformer block: same rows, different dY / X)
+// in ONE launch: the output tiles of all problems share the chip, so the contraction is split 2-5 ways instead of 7-28 ways per
+// problem - a few large partial slabs and one reduce launch per block instead of four of each.
+struct TnProb {
+    const bf16_t* A; const bf16_t* B; float* C; float* partial;
+    int M, N, tiles_m, tiles_n;
+    int64_t lda, ldb, ldc;
+    int first;   // first workgroup of the problem
+};
+struct TnGroup {
+    TnProb prob[4];
+    int n, total, K, splits, k_per_split;
+    float alpha, beta;
+};
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_group_kernel(TnGroup g) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TB_OPER];
+    const int id = xcd_remap(blockIdx.x, g.total);
+    int k = 0;
+    if (g.n > 1 && id >= g.prob[1].first) k = 1;
+    if (g.n > 2 && id >= g.prob[2].first) k = 2;
+    if (g.n > 3 && id >= g.prob[3].first) k = 3;
+    const TnProb& q = g.prob[k];
+    GemmBf16Params p;
+    p.A = q.A; p.B = q.B; p.C = q.C; p.partial = q.partial;
+    p.M = q.M; p.N = q.N; p.K = g.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+    p.tiles_m = q.tiles_m; p.tiles_n = q.tiles_n; p.splits = g.splits; p.k_per_split = g.k_per_split;
+    p.epi.alpha = g.alpha; p.epi.beta = g.beta;
+    tn_big_body(p, smem, id - q.first);
+}
+// C_k = alpha * sum_s partial_k[s] + beta * C_k for every problem of the group (fixed order), one launch
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(TnGroup g, int4 first_block) {
+    int k = 0;
+    const int b = blockIdx.x;
+    if (g.n > 1 && b >= first_block.y) k = 1;
+    if (g.n > 2 && b >= first_block.z) k = 2;
+    if (g.n > 3 && b >= first_block.w) k = 3;
+    const int fb = k == 0 ? first_block.x : (k == 1 ? first_block.y : (k == 2 ? first_block.z : first_block.w));
+    const TnProb& q = g.prob[k];
+    const int64_t mn = (int64_t)q.M * q.N;
+    const int64_t i4 = ((int64_t)(b - fb) * 256 + threadIdx.x) * 4;
+    if (i4 >= mn) return;
+    f32x4 s = *(const f32x4*)(q.partial + i4);
+    for (int sidx = 1; sidx < g.splits; ++sidx) s += *(const f32x4*)(q.partial + (int64_t)sidx * mn + i4);
+    float* cp = q.C + (i4 / q.N) * q.ldc + (i4 % q.N);
+    f32x4 v = s * g.alpha;
+    if (g.beta != 0.f) v += *(const f32x4*)cp * g.beta;
+    *(f32x4*)cp = v;
 }
 
 // C = alpha * sum_s partial[s] + beta * C   (fixed order); optionally also cs_out = cs_beta * cs_out + sum_s cs_partial[s]
@@ -1558,6 +1611,81 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     if (kind == TN_BIG && colsum_a)   // stream-ordered behind the reduction, so the partial-slab workspace is free again
         return sc_colsum(a, SC_BF16, r, m, lda, colsum_a, colsum_beta != 0.f ? 1 : 0, ws, ws_bytes, (void*)stream);
     return SC_OK;
+}
+
+// ws bytes of a grouped weight-gradient launch
+size_t sc_gemm_bf16_tn_group_ws(int nprob, const int64_t* m, const int64_t* n, int64_t r) {
+    int64_t tiles = 0, elems = 0;
+    for (int k = 0; k < nprob; ++k) { tiles += sc_cdiv(m[k], B_M) * sc_cdiv(n[k], B_N); elems += m[k] * n[k]; }
+    int64_t s = tiles > 0 ? sc_num_cus() / tiles : 1;
+    const int64_t nk = r / KSTEP, cap = nk / 4 > 1 ? nk / 4 : 1;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return s > 1 ? (size_t)s * elems * sizeof(float) : 0;
+}
+
+// dW_k (+)= A_k^T B_k for up to four problems sharing the contraction length r (r % 64 == 0, every M_k, N_k a multiple of 8)
+int sc_gemm_bf16_tn_group_launch(int nprob, const int64_t* m, const int64_t* n, int64_t r, const void* const* a, const int64_t* lda, const void* const* b,
+                                 const int64_t* ldb, float* const* c, const int64_t* ldc, float alpha, float beta, void* ws, size_t ws_bytes,
+                                 hipStream_t stream) {
+    SC_REQUIRE(nprob >= 1 && nprob <= 4 && r > 0 && r % KSTEP == 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn_group: 1..4 problems, r %% 64 == 0");
+    TnGroup g;
+    g.n = nprob; g.K = (int)r; g.alpha = alpha; g.beta = beta;
+    int64_t tiles = 0, elems = 0;
+    for (int k = 0; k < nprob; ++k) {
+        SC_REQUIRE(m[k] > 0 && n[k] > 0 && m[k] % 8 == 0 && n[k] % 8 == 0 && a[k] && b[k] && c[k], SC_ERR_SHAPE, "sc_gemm_bf16_tn_group: bad problem %d", k);
+        SC_REQUIRE(lda[k] % 8 == 0 && ldb[k] % 8 == 0 && ldc[k] % 4 == 0 && lda[k] >= m[k] && ldb[k] >= n[k] && ldc[k] >= n[k], SC_ERR_SHAPE,
+                   "sc_gemm_bf16_tn_group: bad leading dimension (problem %d)", k);
+        SC_REQUIRE(sc_aligned(a[k], 16) && sc_aligned(b[k], 16) && sc_aligned(c[k], 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn_group: operands must be 16-byte aligned");
+        TnProb& q = g.prob[k];
+        q.A = (const bf16_t*)a[k]; q.B = (const bf16_t*)b[k]; q.C = c[k]; q.M = (int)m[k]; q.N = (int)n[k];
+        q.lda = lda[k]; q.ldb = ldb[k]; q.ldc = ldc[k];
+        q.tiles_m = (int)sc_cdiv(m[k], B_M); q.tiles_n = (int)sc_cdiv(n[k], B_N);
+        tiles += (int64_t)q.tiles_m * q.tiles_n; elems += m[k] * n[k];
+    }
+    for (int k = nprob; k < 4; ++k) g.prob[k] = g.prob[0];
+    const int64_t nk = r / KSTEP, cap = nk / 4 > 1 ? nk / 4 : 1;
+    int64_t s = sc_num_cus() / tiles;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    g.k_per_split = (int)sc_cdiv(nk, s);
+    g.splits = (int)sc_cdiv(nk, g.k_per_split);
+    float* slab = (float*)ws;
+    if (g.splits > 1) {
+        SC_REQUIRE(ws && sc_aligned(ws, 16) && ws_bytes >= (size_t)g.splits * elems * sizeof(float), SC_ERR_WORKSPACE, "sc_gemm_bf16_tn_group: workspace too small");
+    }
+    int first = 0;
+    int fb[4] = {0, 0, 0, 0};
+    int blocks = 0;
+    for (int k = 0; k < nprob; ++k) {
+        TnProb& q = g.prob[k];
+        q.first = first;
+        first += q.tiles_m * q.tiles_n * g.splits;
+        q.partial = g.splits > 1 ? slab : nullptr;
+        slab += (size_t)g.splits * m[k] * n[k];
+        fb[k] = blocks;
+        blocks += (int)sc_cdiv(m[k] * n[k] / 4, 256);
+    }
+    for (int k = nprob; k < 4; ++k) fb[k] = blocks;
+    g.total = first;
+    hipLaunchKernelGGL(gemm_bf16_tn_group_kernel, dim3((unsigned)g.total), dim3(512), 0, stream, g);
+    SC_CHECK_LAUNCH();
+    if (g.splits > 1) {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, int4{fb[0], fb[1], fb[2], fb[3]});
+        SC_CHECK_LAUNCH();
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_gemm_bf16_tn_group(int nprob, const int64_t* m, const int64_t* n, int64_t r, const void* const* a, const int64_t* lda,
+                                     const void* const* b, const int64_t* ldb, float* const* c, const int64_t* ldc, float alpha, float beta, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    SC_REQUIRE(m && n && a && lda && b && ldb && c && ldc, SC_ERR_ARG, "sc_gemm_bf16_tn_group: null argument");
+    return sc_gemm_bf16_tn_group_launch(nprob, m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" size_t sc_gemm_bf16_tn_group_workspace_bytes(int nprob, const int64_t* m, const int64_t* n, int64_t r) {
+    if (!m || !n || nprob < 1 || nprob > 4 || r <= 0) return 0;
+    return sc_gemm_bf16_tn_group_ws(nprob, m, n, r);
 }
 
 extern "C" int sc_gemm_bf16_nt(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc,

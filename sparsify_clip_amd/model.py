@@ -101,6 +101,7 @@ class ClipModel:
         self._scratch = {}
         self._aux_stream, self.wt_ready = None, None
         self._side = None      # side stream of the weight-gradient GEMMs (bf16 path)
+        self._wt_batch = None  # batched launcher of the [in,out] weight copies
         self.init_parameters(seed)
 
     # ------------------------------------------------------------------------------------------ layout
@@ -279,15 +280,18 @@ class ClipModel:
             torch.cuda.current_stream().wait_event(self.wt_ready)
 
     def _rebuild_wt(self):
-        for tower in (self.visual, self.text):
-            for i in range(tower.layers):
-                for k in GEMM_WEIGHTS:
-                    name = f"{tower.prefix}{i}.{k}"
-                    src = self.param(name)
-                    dst = self.wt.get(name)
-                    if dst is None:
+        """bf16 [in,out] copies of every block GEMM weight from the fp32 masters: one batched launch over a pointer table."""
+        if self._wt_batch is None:
+            pairs = []
+            for tower in (self.visual, self.text):
+                for i in range(tower.layers):
+                    for k in GEMM_WEIGHTS:
+                        name = f"{tower.prefix}{i}.{k}"
+                        src = self.param(name)
                         dst = self.wt[name] = torch.empty(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=self.device)
-                    ops.transpose_cast_bf16(src, dst)
+                        pairs.append((src, dst))
+            self._wt_batch = ops.transpose_cast_bf16_batch(pairs)
+        self._wt_batch()
 
     # ------------------------------------------------------------------------------------------ buffers
     def _buf(self, key, shape, dtype):

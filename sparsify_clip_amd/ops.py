@@ -93,6 +93,24 @@ def gemm_bf16_tn(a, b, out=None, alpha=1.0, beta=0.0, colsum_out=None, colsum_be
     return out
 
 
+def gemm_bf16_tn_group(problems, alpha=1.0, beta=0.0):
+    """problems: up to four (a [R,M] bf16, b [R,N] bf16, out [M,N] fp32) sharing R: out = alpha * a^T b + beta * out, ONE launch."""
+    n = len(problems)
+    r = problems[0][0].shape[0]
+    I64, VP = ctypes.c_int64 * n, ctypes.c_void_p * n
+    m = I64(*[p[0].shape[1] for p in problems])
+    nn = I64(*[p[1].shape[1] for p in problems])
+    for a, b, c in problems:
+        require_gpu(a, "a", torch.bfloat16), require_gpu(b, "b", torch.bfloat16), require_gpu(c, "out", torch.float32)
+        if a.shape[0] != r or b.shape[0] != r or tuple(c.shape) != (a.shape[1], b.shape[1]):
+            raise ScError("gemm_bf16_tn_group: shapes disagree")
+    nbytes = LIB.raw("sc_gemm_bf16_tn_group_workspace_bytes")(n, m, nn, r)
+    ws = _workspace(nbytes, problems[0][0].device)
+    LIB.call("sc_gemm_bf16_tn_group", n, m, nn, r, VP(*[p[0].data_ptr() for p in problems]), m, VP(*[p[1].data_ptr() for p in problems]), nn,
+             VP(*[p[2].data_ptr() for p in problems]), nn, float(alpha), float(beta), ptr(ws), ws.numel(), stream_ptr())
+    return [p[2] for p in problems]
+
+
 # ------------------------------------------------------------------------------------------------ loss head
 def _loss_ws(b, e, device):
     n = LIB.raw("sc_loss_workspace_bytes")(b, e)
@@ -332,6 +350,21 @@ def transpose_cast_bf16(src, dst=None):
         dst = torch.empty(cols, rows, dtype=torch.bfloat16, device=src.device)
     LIB.call("sc_transpose_cast_bf16", ptr(src), rows, cols, ptr(dst), stream_ptr())
     return dst
+
+
+def transpose_cast_bf16_batch(pairs):
+    """pairs: list of (src fp32 [r,c], dst bf16 [c,r]) -> a launcher that redoes all the transposes in ONE kernel launch."""
+    rows, first = [], 0
+    for src, dst in pairs:
+        r, c = src.shape
+        rows.append([src.data_ptr(), dst.data_ptr(), r, c, first])
+        first += ((r + 31) // 32) * ((c + 31) // 32)
+    table = torch.tensor(rows, dtype=torch.int64, device=pairs[0][0].device)
+
+    def run():
+        LIB.call("sc_transpose_cast_bf16_batch", ptr(table), len(rows), first, stream_ptr())
+    run.table = table
+    return run
 
 
 def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

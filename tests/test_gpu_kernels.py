@@ -468,6 +468,13 @@ def test_colsum_cast_transpose(ops):
     src = rnd(70, 130, seed=62)
     assert torch.equal(ops.cast_bf16(src.to(DEV)).cpu(), src.to(torch.bfloat16))
     assert torch.equal(ops.transpose_cast_bf16(src.to(DEV)).cpu(), src.t().contiguous().to(torch.bfloat16))
+    # the batched form (one launch over a pointer table): ragged sizes, every item
+    srcs = [rnd(r, c, seed=63 + k).to(DEV) for k, (r, c) in enumerate([(70, 130), (32, 32), (1, 97), (257, 64), (768, 3072)])]
+    dsts = [torch.zeros(t.shape[1], t.shape[0], dtype=torch.bfloat16, device=DEV) for t in srcs]
+    run = ops.transpose_cast_bf16_batch(list(zip(srcs, dsts)))
+    run()
+    for t, d in zip(srcs, dsts):
+        assert torch.equal(d, t.t().contiguous().to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -591,3 +598,30 @@ def test_gemm_kernel_variants_shipped_in_the_library(ops, env_key, env_val):
     bad = q.get(timeout=600)
     p.join(60)
     assert p.exitcode == 0 and bad == [], (env_key, env_val, bad)
+
+
+@pytest.mark.parametrize("r,w", [(4096, 256), (5120, 512), (1024, 768)])
+def test_gemm_bf16_tn_group(ops, r, w):
+    """The four weight gradients of a block in one launch (sc_gemm_bf16_tn_group): each equals the single-problem TN GEMM result
+    within fp32 reassociation (the contraction is split differently), overwrite and accumulate, bit-stable run to run."""
+    shapes = [(w, 4 * w), (4 * w, w), (w, w), (3 * w, w)]
+    probs, want = [], []
+    for k, (m, n) in enumerate(shapes):
+        a = rnd(r, m, seed=200 + k, dtype=torch.bfloat16).to(DEV)
+        b = rnd(r, n, seed=210 + k, dtype=torch.bfloat16).to(DEV)
+        c = torch.full((m, n), 0.5, device=DEV)
+        probs.append((a, b, c))
+        want.append(a.double().t() @ b.double())
+    ops.gemm_bf16_tn_group(probs, beta=1.0)
+    for (a, b, c), w64 in zip(probs, want):
+        assert_close(c, w64 + 0.5, 1e-4, 2e-3 * np.sqrt(r) * 0.05, "grouped dW (accumulate)")
+    first = [p[2].clone() for p in probs]
+    ops.gemm_bf16_tn_group(probs, beta=0.0)
+    for (a, b, c), w64 in zip(probs, want):
+        assert_close(c, w64, 1e-4, 2e-3 * np.sqrt(r) * 0.05, "grouped dW (overwrite)")
+    again = [p[2].clone() for p in probs]
+    ops.gemm_bf16_tn_group(probs, beta=0.0)
+    assert all(torch.equal(x, p[2]) for x, p in zip(again, probs))
+    assert all(not torch.equal(x, y) for x, y in zip(first, again))
+    ops.gemm_bf16_tn_group(probs[:2], beta=0.0)       # fewer than four problems
+    assert_close(probs[1][2], want[1], 1e-4, 2e-3 * np.sqrt(r) * 0.05, "two problems")
