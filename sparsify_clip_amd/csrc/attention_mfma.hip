@@ -98,19 +98,25 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// TWO waves per (batch, head), four heads per 512-thread workgroup: the two waves share the head's LDS images (Q, K, dO) and take
+// alternate query tiles in pass 1 / alternate key tiles in pass 2, so a CU holds two waves per SIMD instead of one with the same
+// LDS footprint - the one-wave form spent 72 % of its wave cycles in s_waitcnt (profiles/r02_attention_pmc_counters.txt) with
+// nothing to switch to.  Workgroup barriers: after staging, between the passes (row statistics), before the column-sum hand-over.
 template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
+__global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
                                                             float scale, float* cs_part /* [batch][3 W] column sums of d_qkv per image, or null */) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;                 // elements per LDS image
-    constexpr int WAVE_ELEMS = 3 * IMG + 3 * NT * 16 * 2;   // 3 images + 3 fp32 stat rows (2 bf16 slots per float)
+    constexpr int HEAD_ELEMS = 3 * IMG + 3 * NT * 16 * 2;   // 3 images + 3 fp32 stat rows (2 bf16 slots per float)
     extern __shared__ __attribute__((aligned(16))) bf16_t lds_bwd[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int head = blockIdx.x * 4 + wave;
-    if (head >= total_heads) return;
-    bf16_t* Ks = lds_bwd + wave * WAVE_ELEMS;
+    const int slot = wave >> 1, half = wave & 1;        // head slot of the workgroup, which of its two waves
+    const int head_raw = blockIdx.x * 4 + slot;
+    const bool valid = head_raw < total_heads;           // a surplus slot repeats the last head's work and stores nothing (no early exit: barriers)
+    const int head = valid ? head_raw : total_heads - 1;
+    bf16_t* Ks = lds_bwd + slot * HEAD_ELEMS;
     bf16_t* Qs = Ks + IMG;
     bf16_t* Os = Qs + IMG;                              // dO
     float* st_m = (float*)(Os + IMG);                   // [NT*16] row max
@@ -122,9 +128,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
     const bf16_t* vb = qb + 2 * W;
     const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
     bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
-    stage_head<NT>(Qs, qb, ld, S, lane);
-    stage_head<NT>(Ks, qb + W, ld, S, lane);
-    stage_head<NT>(Os, dob, W, S, lane);
+    stage_head_half<NT>(Qs, qb, ld, S, lane, half);
+    stage_head_half<NT>(Ks, qb + W, ld, S, lane, half);
+    stage_head_half<NT>(Os, dob, W, S, lane, half);
+    __syncthreads();
     const int g = lane >> 4, c16 = lane & 15;
 
     bf16x8 Vf[NT][2];     // V row fragments (rows = keys), used as A in pass 1 and as B in pass 2
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) csq[dt] = csk[dt] = csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---------------- pass 1: lane = query row i.  P, dS in registers -> dQ ; row statistics -> LDS
-    for (int it = 0; it < n_t; ++it) {
+    for (int it = half; it < n_t; it += 2) {
         const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
         const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
         const int i = it * 16 + c16;
@@ -216,15 +223,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
                 dq[dt] = MFMA16(kt, dsf, dq[dt]);
             }
         }
-        if (i < S) {
+        if (i < S && valid) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
         }
         if (cs_part) cs_add(csq, dq, i < S);
     }
+    __syncthreads();   // the row statistics of BOTH waves' query tiles are in LDS
     // statistics rows of the padding tile (only read when NT is odd and the last k-step is half empty: never) stay untouched
     // ---------------- pass 2: lane = key row j.  P^T, dS^T products -> dV, dK
-    for (int jt = 0; jt < n_t; ++jt) {
+    for (int jt = half; jt < n_t; jt += 2) {
         const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
         const bf16x8 v0 = row_frag_global(vb, ld, jt, 0, lane, S), v1 = row_frag_global(vb, ld, jt, 1, lane, S);   // runtime jt: not Vf[jt] (scratch)
         const int j = jt * 16 + c16;
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
                 dk[dt] = MFMA16(qt, dsf, dk[dt]);
             }
         }
-        if (j < S) {
+        if (j < S && valid) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 io<bf16_t>::st4(dqb + (int64_t)j * ld + W + 16 * dt + 4 * g, dk[dt]);
@@ -275,15 +283,26 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* qkv, c
         }
         if (cs_part) { cs_add(csk, dk, j < S); cs_add(csv, dv, j < S); }
     }
-    if (cs_part) {   // this wave is the only producer of its head's 192 columns for image b
+    if (cs_part) {   // the head's two waves are the only producers of its 192 columns for image b: wave 1 hands its sums over, wave 0 adds (fixed order)
         cs_rows(csq); cs_rows(csk); cs_rows(csv);
-        if (c16 == 0) {
+        __syncthreads();                      // every wave is done reading the images: the K image becomes the hand-over buffer
+        float* xch = (float*)Ks;              // [3][4 dt][4 g][4 r] floats
+        if (half == 1 && c16 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(f32x4*)(xch + (0 * 16 + dt * 4 + g) * 4) = csq[dt];
+                *(f32x4*)(xch + (1 * 16 + dt * 4 + g) * 4) = csk[dt];
+                *(f32x4*)(xch + (2 * 16 + dt * 4 + g) * 4) = csv[dt];
+            }
+        }
+        __syncthreads();
+        if (half == 0 && c16 == 0 && valid) {
             float* dst = cs_part + (int64_t)b * 3 * W + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *(f32x4*)(dst + 16 * dt) = csq[dt];
-                *(f32x4*)(dst + W + 16 * dt) = csk[dt];
-                *(f32x4*)(dst + 2 * W + 16 * dt) = csv[dt];
+                *(f32x4*)(dst + 16 * dt) = csq[dt] + *(const f32x4*)(xch + (0 * 16 + dt * 4 + g) * 4);
+                *(f32x4*)(dst + W + 16 * dt) = csk[dt] + *(const f32x4*)(xch + (1 * 16 + dt * 4 + g) * 4);
+                *(f32x4*)(dst + 2 * W + 16 * dt) = csv[dt] + *(const f32x4*)(xch + (2 * 16 + dt * 4 + g) * 4);
             }
         }
     }
@@ -319,10 +338,10 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int
     const dim3 grid((unsigned)sc_cdiv(total, 4));
     if (causal) {
         SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     } else {
         SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false>), grid, dim3(256), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;

@@ -53,6 +53,19 @@ static __device__ __forceinline__ void stage_head(bf16_t* img, const bf16_t* src
     }
 }
 
+// the same by the two waves of a head: wave `half` copies the iterations of its parity
+template <int NT>
+static __device__ __forceinline__ void stage_head_half(bf16_t* img, const bf16_t* src, int64_t ld, int S, int lane, int half) {
+#pragma unroll
+    for (int it2 = 0; it2 < NT; ++it2) {
+        const int it = 2 * it2 + half;
+        const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r < S) v = *(const uint4*)(src + (int64_t)r * ld + c);
+        *(uint4*)(img + r * LDR + c) = v;
+    }
+}
+
 static __device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups that share one query row
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));

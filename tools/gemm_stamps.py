@@ -32,4 +32,16 @@ for (m, n, k), kind in shapes:
     print(f"{kind:14s} [{m}x{n}x{k}] {len(s):5d} stamped tiles: wait {wait.median():6.2f}  loop {loop.median():6.2f}  epilogue {epi_t.median():6.2f} us "
           f"(per tile; MFMA time at peak {ideal:5.2f} us), kernel span {span:7.1f} us; loop p10/p90 {loop.quantile(0.1):.2f}/{loop.quantile(0.9):.2f}, "
           f"epilogue p10/p90 {epi_t.quantile(0.1):.2f}/{epi_t.quantile(0.9):.2f}", flush=True)
+    # per workgroup (static tile list: virtual block id % grid): when does it finish, how much of its span is spent in tiles
+    idx = torch.nonzero(st[:, 3] > 0).squeeze(1).cpu()
+    grid = min(256, len(s))
+    t_begin = s[:, 0].min()
+    end = torch.zeros(grid, dtype=torch.float64)
+    busy = torch.zeros(grid, dtype=torch.float64)
+    for row, vb in zip(s, idx.tolist()):
+        w = vb % grid
+        end[w] = max(end[w], (row[3] - t_begin) / 100.0)
+        busy[w] += (row[3] - row[0]) / 100.0
+    print(f"               workgroup end times (x100 cycles after the first stamp): min {end.min():.0f}  median {end.median():.0f}  max {end.max():.0f};  "
+          f"time inside tiles per workgroup: median {busy.median():.0f}  max {busy.max():.0f}", flush=True)
     del a, b, c, epi, keep, st

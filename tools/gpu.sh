@@ -12,6 +12,7 @@
 #   pmc_traffic  FETCH_SIZE / WRITE_SIZE passes over the replay launch set   -> gpurun_out/gemm_traffic.json
 #   pmc_loss     FETCH_SIZE / WRITE_SIZE + kernel times of the loss head at B = 8192 -> gpurun_out/pmc/loss_counters.txt
 #   loss         tools/loss_bench.py                       -> gpurun_out/loss_head_times.txt
+#   attn / pmc_attn   tools/attn_bench.py timings / SQ counters of the attention kernels -> gpurun_out/attention_times.txt, pmc/attn_counters.txt
 #   dp2          python bench.py --gpus 2 under SC_DIST_BACKEND=gloo on the one GPU (self-launch rehearsal) -> gpurun_out/dp2.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof $R/gpurun_out/pmc $R/gpurun_out/replay
@@ -65,6 +66,12 @@ for task in "$@"; do
       PMC l_fetch FETCH_SIZE -- $R/tools/loss_one.py || exit 1
       PMC l_write WRITE_SIZE GRBM_GUI_ACTIVE -- $R/tools/loss_one.py || exit 1
       python3 tools/pmc_table.py "" $R/gpurun_out/pmc/l_fetch $R/gpurun_out/pmc/l_write > $R/gpurun_out/pmc/loss_counters.txt; cat $R/gpurun_out/pmc/loss_counters.txt ;;
+    pmc_attn)
+      PMC a_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $R/tools/attn_bench.py || exit 1
+      PMC a_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES -- $R/tools/attn_bench.py || exit 1
+      python3 tools/pmc_table.py attn $R/gpurun_out/pmc/a_sq1 $R/gpurun_out/pmc/a_sq2 > $R/gpurun_out/pmc/attn_counters.txt; cat $R/gpurun_out/pmc/attn_counters.txt ;;
+    attn)
+      timeout -k 10 300 python tools/attn_bench.py > gpurun_out/attention_times.txt 2>&1; rc=$?; cat gpurun_out/attention_times.txt; [ $rc = 0 ] || exit $rc ;;
     *) echo "unknown task $task"; exit 2 ;;
   esac
   find $R/gpurun_out/pmc -name "*.csv" -size +8M -delete 2>/dev/null
