@@ -12,6 +12,7 @@
 // LDS images are row-major [rows][64] bf16 with a 144-byte row stride: ds_read_b128 row reads are conflict-free and the
 // transposed reads at most 2-way.  Padded rows are zero-filled, padded keys masked to probability 0.
 #include "attention_mfma_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
 // alternate query tiles in pass 1 / alternate key tiles in pass 2, so a CU holds two waves per SIMD instead of one with the same
 // LDS footprint - the one-wave form spent 72 % of its wave cycles in s_waitcnt (profiles/r02_attention_pmc_counters.txt) with
 // nothing to switch to.  Workgroup barriers: after staging, between the passes (row statistics), before the column-sum hand-over.
-template <int NT, bool CAUSAL>
+template <int NT, bool CAUSAL, int WPH>
 __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
                                                             float scale, float* cs_part /* [batch][3 W] column sums of d_qkv per image, or null */) {
     constexpr int KS = (NT + 1) / 2;
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
     extern __shared__ __attribute__((aligned(16))) bf16_t lds_bwd[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = wave >> 1, half = wave & 1;        // head slot of the workgroup, which of its two waves
-    const int head_raw = blockIdx.x * 4 + slot;
+    const int slot = wave / WPH, half = wave % WPH;     // head slot of the workgroup, which of the head's WPH waves
+    const int head_raw = blockIdx.x * (8 / WPH) + slot;
     const bool valid = head_raw < total_heads;           // a surplus slot repeats the last head's work and stores nothing (no early exit: barriers)
     const int head = valid ? head_raw : total_heads - 1;
     bf16_t* Ks = lds_bwd + slot * HEAD_ELEMS;
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
     const bf16_t* vb = qb + 2 * W;
     const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
     bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
-    stage_head_half<NT>(Qs, qb, ld, S, lane, half);
-    stage_head_half<NT>(Ks, qb + W, ld, S, lane, half);
-    stage_head_half<NT>(Os, dob, W, S, lane, half);
+    stage_head_part<NT, WPH>(Qs, qb, ld, S, lane, half);
+    stage_head_part<NT, WPH>(Ks, qb + W, ld, S, lane, half);
+    stage_head_part<NT, WPH>(Os, dob, W, S, lane, half);
     __syncthreads();
     const int g = lane >> 4, c16 = lane & 15;
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) csq[dt] = csk[dt] = csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---------------- pass 1: lane = query row i.  P, dS in registers -> dQ ; row statistics -> LDS
-    for (int it = half; it < n_t; it += 2) {
+    for (int it = half; it < n_t; it += WPH) {
         const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
         const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
         const int i = it * 16 + c16;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
     __syncthreads();   // the row statistics of BOTH waves' query tiles are in LDS
     // statistics rows of the padding tile (only read when NT is odd and the last k-step is half empty: never) stay untouched
     // ---------------- pass 2: lane = key row j.  P^T, dS^T products -> dV, dK
-    for (int jt = half; jt < n_t; jt += 2) {
+    for (int jt = half; jt < n_t; jt += WPH) {
         const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
         const bf16x8 v0 = row_frag_global(vb, ld, jt, 0, lane, S), v1 = row_frag_global(vb, ld, jt, 1, lane, S);   // runtime jt: not Vf[jt] (scratch)
         const int j = jt * 16 + c16;
@@ -283,16 +284,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
         }
         if (cs_part) { cs_add(csk, dk, j < S); cs_add(csv, dv, j < S); }
     }
-    if (cs_part) {   // the head's two waves are the only producers of its 192 columns for image b: wave 1 hands its sums over, wave 0 adds (fixed order)
+    if (cs_part) {   // the head's WPH waves are the only producers of its 192 columns for image b: waves 1.. hand their sums over, wave 0 adds (fixed order)
         cs_rows(csq); cs_rows(csk); cs_rows(csv);
         __syncthreads();                      // every wave is done reading the images: the K image becomes the hand-over buffer
-        float* xch = (float*)Ks;              // [3][4 dt][4 g][4 r] floats
-        if (half == 1 && c16 == 0) {
+        float* xch = (float*)Ks;              // [WPH - 1][3][4 dt][4 g][4 r] floats
+        if (half != 0 && c16 == 0) {
+            float* x = xch + (half - 1) * 192;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *(f32x4*)(xch + (0 * 16 + dt * 4 + g) * 4) = csq[dt];
-                *(f32x4*)(xch + (1 * 16 + dt * 4 + g) * 4) = csk[dt];
-                *(f32x4*)(xch + (2 * 16 + dt * 4 + g) * 4) = csv[dt];
+                *(f32x4*)(x + (0 * 16 + dt * 4 + g) * 4) = csq[dt];
+                *(f32x4*)(x + (1 * 16 + dt * 4 + g) * 4) = csk[dt];
+                *(f32x4*)(x + (2 * 16 + dt * 4 + g) * 4) = csv[dt];
             }
         }
         __syncthreads();
@@ -300,9 +302,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
             float* dst = cs_part + (int64_t)b * 3 * W + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *(f32x4*)(dst + 16 * dt) = csq[dt] + *(const f32x4*)(xch + (0 * 16 + dt * 4 + g) * 4);
-                *(f32x4*)(dst + W + 16 * dt) = csk[dt] + *(const f32x4*)(xch + (1 * 16 + dt * 4 + g) * 4);
-                *(f32x4*)(dst + 2 * W + 16 * dt) = csv[dt] + *(const f32x4*)(xch + (2 * 16 + dt * 4 + g) * 4);
+                f32x4 q = csq[dt], k = csk[dt], v = csv[dt];
+#pragma unroll
+                for (int o = 0; o < WPH - 1; ++o) {
+                    const float* x = xch + o * 192;
+                    q += *(const f32x4*)(x + (0 * 16 + dt * 4 + g) * 4);
+                    k += *(const f32x4*)(x + (1 * 16 + dt * 4 + g) * 4);
+                    v += *(const f32x4*)(x + (2 * 16 + dt * 4 + g) * 4);
+                }
+                *(f32x4*)(dst + 16 * dt) = q;
+                *(f32x4*)(dst + W + 16 * dt) = k;
+                *(f32x4*)(dst + 2 * W + 16 * dt) = v;
             }
         }
     }
@@ -332,19 +342,26 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total, b
     return SC_OK;
 }
 
-template <int NT>
-int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
-    const size_t lds = (size_t)4 * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
-    const dim3 grid((unsigned)sc_cdiv(total, 4));
+// SC_ATTENTION_WPH=2: two waves per head (four heads per workgroup) instead of four (two heads, two workgroups per CU)
+template <int NT, int WPH>
+int launch_bwd_w(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
+    const size_t lds = (size_t)(8 / WPH) * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
+    const dim3 grid((unsigned)sc_cdiv(total, 8 / WPH));
     if (causal) {
-        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
+        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true, WPH>, lds));
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true, WPH>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     } else {
-        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
+        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false, WPH>, lds));
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false, WPH>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;
+}
+template <int NT>
+int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
+    static const bool two = [] { const char* e = getenv("SC_ATTENTION_WPH"); return e && e[0] == '2'; }();
+    return two ? launch_bwd_w<NT, 2>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st)
+               : launch_bwd_w<NT, 4>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
 }
 
 }  // namespace

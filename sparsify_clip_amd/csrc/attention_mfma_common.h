@@ -53,12 +53,13 @@ static __device__ __forceinline__ void stage_head(bf16_t* img, const bf16_t* src
     }
 }
 
-// the same by the two waves of a head: wave `half` copies the iterations of its parity
-template <int NT>
-static __device__ __forceinline__ void stage_head_half(bf16_t* img, const bf16_t* src, int64_t ld, int S, int lane, int half) {
+// the same by the WPH waves of a head: wave `part` copies every WPH-th group of 8 rows
+template <int NT, int WPH>
+static __device__ __forceinline__ void stage_head_part(bf16_t* img, const bf16_t* src, int64_t ld, int S, int lane, int part) {
 #pragma unroll
-    for (int it2 = 0; it2 < NT; ++it2) {
-        const int it = 2 * it2 + half;
+    for (int it2 = 0; it2 < (2 * NT + WPH - 1) / WPH; ++it2) {
+        const int it = WPH * it2 + part;
+        if (it >= 2 * NT) break;
         const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
         uint4 v = {0u, 0u, 0u, 0u};
         if (r < S) v = *(const uint4*)(src + (int64_t)r * ld + c);
