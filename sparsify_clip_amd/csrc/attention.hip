@@ -26,13 +26,9 @@ bool use_mfma() {
     static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return !(e && e[0] == 'v'); }();
     return on;
 }
-// SC_ATTENTION=wave: the backward at seq <= 64 on the one-wave-per-head kernel instead of one workgroup per head (A/B runs)
+// SC_ATTENTION_SHORT=2: the recompute (workgroup-per-head) kernels for short sequences too (A/B runs)
 bool short_recompute() {
     static const bool on = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
-    return on;
-}
-bool wave_per_head() {
-    static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return e && e[0] == 'w'; }();
     return on;
 }
 
@@ -315,8 +311,9 @@ int attention_bwd_impl(const void* qkv, const void* d_out, void* d_qkv, int dtyp
     SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
-        // backward: one workgroup per head wins at seq <= 64 (262 vs 303 us, S = 50), one wave per head at 64 < seq <= 80 (286 vs 341 us, S = 77)
-        int rc = short_recompute() ? 1 : (wave_per_head() || seq > 64) ? sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream) : 1;
+        // backward, seq <= 80: two waves per head on shared LDS images (208 us at S = 77, 242 us at S = 50; one wave per head: 286 / 303 us,
+        // one workgroup per head: 341 / 262 us)
+        int rc = short_recompute() ? 1 : sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream);
         if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream);
         if (rc != 1) {
             if (cs_done) *cs_done = rc == SC_OK && cs_part != nullptr;

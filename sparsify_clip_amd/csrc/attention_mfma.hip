@@ -342,7 +342,7 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total, b
     return SC_OK;
 }
 
-// SC_ATTENTION_WPH=2: two waves per head (four heads per workgroup) instead of four (two heads, two workgroups per CU)
+// WPH = 2 (four heads per workgroup) measured 208 / 242 us at S = 77 / 50 against 250 / 276 us for WPH = 4 (profiles/r02_attention_times.txt)
 template <int NT, int WPH>
 int launch_bwd_w(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
     const size_t lds = (size_t)(8 / WPH) * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
@@ -359,9 +359,7 @@ int launch_bwd_w(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, i
 }
 template <int NT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
-    static const bool two = [] { const char* e = getenv("SC_ATTENTION_WPH"); return e && e[0] == '2'; }();
-    return two ? launch_bwd_w<NT, 2>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st)
-               : launch_bwd_w<NT, 4>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
+    return launch_bwd_w<NT, 2>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
 }
 
 }  // namespace
