@@ -7,11 +7,28 @@
 // partial sums, so every scalar is bit-stable run to run (no float atomics).
 #include "common.h"
 #include "gemm_epilogue.h"
+#include <stdlib.h>
 
 int sc_gemm_f32_launch(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float* a, int64_t lda,
                        const float* b, int64_t ldb, float* c, int64_t ldc, const EpiParams& epi, hipStream_t stream);
 
+// fused pairwise kernels (pairwise.hip): no [B,B] matrix
+bool sc_pair_supported(int64_t b, int64_t e);
+size_t sc_pair_workspace_bytes(int64_t b, int64_t e);
+int sc_pair_contrastive(const float* img, const float* txt, int64_t b, int64_t e, float inv_temp, float grad_scale, float* rowv, float* colv, float* diag,
+                        float* d_img, float* d_txt, float** dtemp_part, int* n_dtemp, void* ws, hipStream_t st);
+int sc_pair_lunif(const float* x, const float* sumsq, int64_t b, int64_t e, float t, float* rowsum, float* wx, void* ws, hipStream_t st);
+int sc_pair_sparsify(const float* x, int64_t b, int64_t e, float grad_scale, float* loss_out, float* dx, float* scratch_be, void* ws, hipStream_t st);
+
 namespace {
+
+// SC_LOSS_FUSED=0: the round-1 path (fp32 MFMA GEMMs on a materialised [B,B] matrix) for every shape (A/B; it stays the path of
+// batches that are not a multiple of 64 and of widths that are not a multiple of 128)
+bool fused_on() {
+    static const bool on = [] { const char* e = getenv("SC_LOSS_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+bool use_fused(int64_t b, int64_t e) { return fused_on() && sc_pair_supported(b, e); }
 
 constexpr int COL_CHUNKS = 64;   // row chunks of the column-statistics pass
 constexpr int RED_BLOCKS = 1024; // partial sums of the matrix sweeps
@@ -36,7 +53,8 @@ size_t ws_layout(int64_t b, int64_t e, void* base, LossWs* w) {
         return p;
     };
     LossWs l;
-    l.mat = take((size_t)b * b);
+    // fused path: the [B,B] slot is replaced by the pairwise kernels' own workspace (operand splits, partial slabs, per-tile statistics)
+    l.mat = use_fused(b, e) ? take((sc_pair_workspace_bytes(b, e) + 3) / 4) : take((size_t)b * b);
     l.tmp = take((size_t)b * e);
     l.rowv = take(b);
     l.colv = take(b);
@@ -409,6 +427,15 @@ extern "C" int sc_contrastive_fwd_bwd(const float* img, const float* txt, int64_
     LossWs w;
     ws_layout(b, e, ws, &w);
     const float inv_t = 1.0f / temperature;
+    if (use_fused(b, e)) {   // tile sweeps on the bf16 matrix cores: LSE partials, then the recomputed tiles times T / I
+        float* gv = nullptr;
+        int ngv = 0;
+        SC_TRY(sc_pair_contrastive(img, txt, b, e, inv_t, grad_scale, w.rowv, w.colv, w.diag, d_img, d_txt, (d_img && d_temp) ? &gv : nullptr, &ngv, w.mat, st));
+        hipLaunchKernelGGL(contrastive_loss_kernel, dim3(1), dim3(256), 0, st, w.rowv, w.colv, w.diag, b, loss_out);
+        if (gv) hipLaunchKernelGGL(dtemp_final_kernel, dim3(1), dim3(256), 0, st, gv, ngv, inv_t, d_temp);
+        SC_CHECK_LAUNCH();
+        return SC_OK;
+    }
     // logits = I T^T / temperature   (:119-120)
     SC_TRY(sc_gemm_f32_launch(0, 1, b, b, e, img, e, txt, e, w.mat, b, epi_plain(inv_t), st));
     hipLaunchKernelGGL(row_stats_kernel<0>, dim3(rows4(b)), dim3(256), 0, st, w.mat, b, w.rowv, w.diag);
@@ -438,6 +465,13 @@ extern "C" int sc_lunif_fwd_bwd(const float* x, int64_t b, int64_t e, float t, f
     ws_layout(b, e, ws, &w);
     hipLaunchKernelGGL(row_sumsq_kernel, dim3(rows4(b)), dim3(256), 0, st, x, b, e, w.colv);
     SC_CHECK_LAUNCH();
+    if (use_fused(b, e)) {   // one sweep gives the row sums of W and W X; nothing of size [B,B] exists
+        SC_TRY(sc_pair_lunif(x, w.colv, b, e, t, w.rowv, w.tmp, w.mat, st));
+        hipLaunchKernelGGL(lunif_loss_kernel, dim3(1), dim3(256), 0, st, w.rowv, b, loss_out, w.scal);
+        if (d_x) hipLaunchKernelGGL(lunif_grad_kernel, dim3((unsigned)sc_cdiv(b * e, 256)), dim3(256), 0, st, x, w.tmp, w.rowv, w.scal, b, e, t, grad_scale, d_x);
+        SC_CHECK_LAUNCH();
+        return SC_OK;
+    }
     // W_ij = exp(-t * max(|xi|^2 + |xj|^2 - 2 xi.xj, 0)), zero diagonal   (:161-164 via the Gram matrix)
     EpiParams ep = epi_plain();
     ep.mode = 1; ep.rowv = w.colv; ep.colv = w.colv; ep.t = t;
@@ -476,6 +510,7 @@ extern "C" int sc_sparsify_fwd_bwd(const float* x, int64_t b, int64_t e, float g
     SC_REQUIRE(x && loss_out, SC_ERR_ARG, "sc_sparsify_fwd_bwd: null argument");
     LossWs w;
     ws_layout(b, e, ws, &w);
+    if (use_fused(b, e)) return sc_pair_sparsify(x, b, e, grad_scale, loss_out, d_x, w.tmp, w.mat, st);
     SC_TRY(sc_gemm_f32_launch(0, 1, b, b, e, x, e, x, e, w.mat, b, epi_plain(), st));
     const int nb = red_blocks(b);
     hipLaunchKernelGGL(sparsify_diff_kernel, dim3(nb), dim3(256), 0, st, w.mat, b, w.part);

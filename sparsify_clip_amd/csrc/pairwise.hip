@@ -1,0 +1,476 @@
+// Fused global-batch loss head: the [B,B] similarity / Gram matrix is never stored.
+//
+// Reference arithmetic: contrastive_loss (sparsify_clip.py:110-132), lunif_loss (:159-164, pdist^2 via the Gram matrix),
+// sparsify_loss (:166-176).  Each term is  (1) a B x B tile sweep  S = X Y^T  on the bf16 MFMA units,  (2) an elementwise map of
+// the tile in registers (logits -> log-sum-exp partials / softmax gradient, squared distance -> exp, Gram -> residual) and, for
+// the gradient,  (3) a second product  O += f(S) Z  against the rows of the other matrix - recomputing (1) instead of reading a
+// stored matrix back.  Row / column statistics leave a tile as fixed-order per-tile partials (no atomics), so every result is
+// bit-stable run to run.
+//
+// fp32 accuracy on bf16 matrix cores: every fp32 operand is split as x = hi + lo (hi = bf16(x), lo = bf16(x - hi), |x - hi - lo| <=
+// 2^-17 |x|) and a product is three MFMAs, hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-18 relative) with fp32 accumulation:
+// 3/16 of the cost of the exact fp32 MFMA path (gemm_f32.hip) at an error far below the 1e-4 bar of the golden fixtures.
+//
+// Tiling: a workgroup (8 waves) owns 64 rows i and sweeps column tiles of 64 rows j (a slice of them when the sweep is split
+// for occupancy).  Per column tile: S[64,64] over K = E in 64-wide slices staged through LDS (hi and lo of both operands);
+// f(S) is written to LDS as a bf16 hi/lo pair (the A operand of the second product); O[64,E] += P[64,64] Z_j[64,E] with every wave
+// owning E/8 output columns and reading its rows of Z^T (a [E,B] copy made once per call) straight from global memory.
+#include "common.h"
+
+namespace {
+
+constexpr int PT = 64;            // tile rows (i) and columns (j)
+constexpr int PK = 64;            // K slice of the first product
+constexpr int LDP = 72;           // LDS row stride in bf16 elements (144 B: conflict-free 16-byte row reads)
+constexpr int SLICE = PT * LDP;   // elements of one staged [64][64] slice
+
+enum { PM_CON_STATS = 0, PM_CON_GRAD = 1, PM_UNIF = 2, PM_SPARS = 3 };
+
+struct PairParams {
+    const bf16_t *xh, *xl;      // [B][E] rows i
+    const bf16_t *yh, *yl;      // [B][E] rows j
+    const bf16_t *zth, *ztl;    // [E][B] transposed hi / lo of the matrix the second product multiplies (gradient modes)
+    int B, E, nsplit, jt_per_split;
+    float inv_temp, t;
+    float coef_row, coef_col, coef_diag;   // CON_GRAD: G = coef_row exp(v - r_i) + coef_col exp(v - c_j) - coef_diag [i == j]
+    const float* rowv;          // CON_GRAD: row LSE r_i (rows i);  UNIF: |x_i|^2
+    const float* colv;          // CON_GRAD: column LSE c_j (rows j); UNIF: |y_j|^2
+    float* opart;               // [nsplit][B][E] partial second products
+    float *rp_m, *rp_s;         // CON_STATS: [jtiles][B] partial row (max, sum exp)
+    float *cp_m, *cp_s;         // CON_STATS: [itiles][B] partial column (max, sum exp)
+    float* diag;                // CON_STATS: [B] logits on the diagonal
+    float* spart;               // UNIF: [nsplit][B] partial row sums of W
+    float* scal_part;           // CON_GRAD: sum G v ; SPARS: sum D^2 - one float per workgroup [itiles * nsplit]
+};
+
+__device__ __forceinline__ unsigned pack_hi(float a, float b, float& ra, float& rb) {   // two bf16 hi parts + the residuals
+    const bf16_t ha = f32_to_bf16(a), hb = f32_to_bf16(b);
+    ra = a - bf16_to_f32(ha); rb = b - bf16_to_f32(hb);
+    return (unsigned)ha | ((unsigned)hb << 16);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
+
+#define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// fp32 [B][E] -> bf16 hi / lo [B][E]; with_t: also the transposed copies [E][B] (32x32 tiles through LDS)
+__global__ __launch_bounds__(256) void split_kernel(const float* x, int B, int E, bf16_t* hi, bf16_t* lo, bf16_t* hi_t, bf16_t* lo_t) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (r < B && c < E) {
+            v = x[(int64_t)r * E + c];
+            const bf16_t h = f32_to_bf16(v);
+            hi[(int64_t)r * E + c] = h;
+            lo[(int64_t)r * E + c] = f32_to_bf16(v - bf16_to_f32(h));
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    if (!hi_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < E && r < B) {
+            const float v = tile[tx][ty + 8 * k];
+            const bf16_t h = f32_to_bf16(v);
+            hi_t[(int64_t)c * B + r] = h;
+            lo_t[(int64_t)c * B + r] = f32_to_bf16(v - bf16_to_f32(h));
+        }
+    }
+}
+
+// online (max, sum exp) merge
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { m = mn; s = 0.f; return; }
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+template <int MODE, int NT2 /* E / 128: 16-column output tiles per wave of the second product */>
+__global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
+    constexpr bool GRAD = MODE != PM_CON_STATS;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[6 * SLICE];   // Xh Xl Yh Yl slices + Ph Pl: 55 296 B
+    __shared__ float xrow[2][PT][2];     // per (wc, i): row partial (max / sum or sum)
+    __shared__ float xcol[4][PT][2];     // per (wr, j): column partial
+    __shared__ float xred[8];
+    bf16_t* Xh = smem; bf16_t* Xl = Xh + SLICE; bf16_t* Yh = Xl + SLICE; bf16_t* Yl = Yh + SLICE; bf16_t* Ph = Yl + SLICE; bf16_t* Pl = Ph + SLICE;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int it = blockIdx.x, split = blockIdx.y;
+    const int i0 = it * PT;
+    const int E = p.E, B = p.B;
+    const int jt0 = split * p.jt_per_split, jt1 = min(B / PT, jt0 + p.jt_per_split);
+    // staging: thread -> (row t >> 3, 16-byte chunk t & 7) of every [64][64] slice
+    const int srow = t >> 3, schunk = (t & 7) * 8;
+    const int64_t xoff = (int64_t)(i0 + srow) * E + schunk;
+    const int soff = srow * LDP + schunk;
+    const int i_lane = i0 + 16 * wr + c16;                       // this lane's row i in the first product
+    float rowc = 0.f;
+    if (MODE == PM_CON_GRAD || MODE == PM_UNIF) rowc = p.rowv[i_lane];
+
+    f32x4 oacc[4][NT2 > 0 ? NT2 : 1];
+    if (GRAD) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) oacc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float rsum = 0.f;        // UNIF: running row sums of W (this lane's i over this wave's columns)
+    float scal = 0.f;        // CON_GRAD: sum G v; SPARS: sum D^2
+    const int EC = NT2 * 16;                                   // output columns per wave of the second product
+    const int nk = E / PK;
+
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int j0 = jt * PT;
+        const int64_t yoff = (int64_t)(j0 + srow) * E + schunk;
+        // ---- first product: S'[j][i] over K = E
+        f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        uint4 rxh = *(const uint4*)(p.xh + xoff), rxl = *(const uint4*)(p.xl + xoff);
+        uint4 ryh = *(const uint4*)(p.yh + yoff), ryl = *(const uint4*)(p.yl + yoff);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                                   // the previous slice (and the previous P tile) has been consumed
+            *(uint4*)(Xh + soff) = rxh; *(uint4*)(Xl + soff) = rxl; *(uint4*)(Yh + soff) = ryh; *(uint4*)(Yl + soff) = ryl;
+            if (kt + 1 < nk) {
+                const int ko = (kt + 1) * PK;
+                rxh = *(const uint4*)(p.xh + xoff + ko); rxl = *(const uint4*)(p.xl + xoff + ko);
+                ryh = *(const uint4*)(p.yh + yoff + ko); ryl = *(const uint4*)(p.yl + yoff + ko);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int fo = (16 * wr + c16) * LDP + 32 * ks + 8 * g;
+                const bf16x8 ah = *(const bf16x8*)(Xh + fo), al = *(const bf16x8*)(Xl + fo);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int bo = (16 * (2 * wc + c) + c16) * LDP + 32 * ks + 8 * g;
+                    const bf16x8 bh = *(const bf16x8*)(Yh + bo), bl = *(const bf16x8*)(Yl + bo);
+                    sc[c] = PMFMA(bh, ah, sc[c]);
+                    sc[c] = PMFMA(bl, ah, sc[c]);
+                    sc[c] = PMFMA(bh, al, sc[c]);
+                }
+            }
+        }
+        // lane: row i_lane, columns j = j0 + 16 (2 wc + c) + 4 g + r
+        // second product's B operand (this wave's rows e of Z^T, k = j): requested now, consumed after the map + the P barrier
+        bf16x8 zh0[NT2 > 0 ? NT2 : 1], zl0[NT2 > 0 ? NT2 : 1], zh1[NT2 > 0 ? NT2 : 1], zl1[NT2 > 0 ? NT2 : 1];
+        if (GRAD) {
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) {
+                const int64_t zo = (int64_t)(wave * EC + 16 * n + c16) * B + j0 + 8 * g;
+                zh0[n] = *(const bf16x8*)(p.zth + zo);
+                zl0[n] = *(const bf16x8*)(p.ztl + zo);
+                zh1[n] = *(const bf16x8*)(p.zth + zo + 32);
+                zl1[n] = *(const bf16x8*)(p.ztl + zo + 32);
+            }
+        }
+        // ---- elementwise map
+        if (MODE == PM_CON_STATS) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[c][r] *= p.inv_temp; m = fmaxf(m, sc[c][r]); }
+            // row partial over this wave's 32 columns
+            float mr = fmaxf(m, __shfl_xor(m, 16, 64));
+            mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+            float sr = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sr += __expf(sc[c][r] - mr);
+            sr += __shfl_xor(sr, 16, 64);
+            sr += __shfl_xor(sr, 32, 64);
+            // column partial over this wave's 16 rows: per (c, r) reduce over the 16 lanes of a lane group
+            float cm[2][4], cs[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = sc[c][r];
+                    x = fmaxf(x, __shfl_xor(x, 1, 64)); x = fmaxf(x, __shfl_xor(x, 2, 64));
+                    x = fmaxf(x, __shfl_xor(x, 4, 64)); x = fmaxf(x, __shfl_xor(x, 8, 64));
+                    float e = __expf(sc[c][r] - x);
+                    e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64); e += __shfl_xor(e, 4, 64); e += __shfl_xor(e, 8, 64);
+                    cm[c][r] = x; cs[c][r] = e;
+                }
+            __syncthreads();                                   // exchange arrays free (previous tile's readers are done)
+            if (g == 0) { xrow[wc][16 * wr + c16][0] = mr; xrow[wc][16 * wr + c16][1] = sr; }
+            if (c16 == 0) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jl = 16 * (2 * wc + c) + 4 * g + r;
+                        xcol[wr][jl][0] = cm[c][r]; xcol[wr][jl][1] = cs[c][r];
+                    }
+            }
+            if (it == jt) {   // diagonal logits: i == j  <=>  16 wr + c16 == 16 (2 wc + c) + 4 g + r
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * wr + c16 == 16 * (2 * wc + c) + 4 * g + r) p.diag[i_lane] = sc[c][r];
+            }
+            __syncthreads();
+            if (t < PT) {            // rows: merge the two column halves in a fixed order
+                float m0 = xrow[0][t][0], s0 = xrow[0][t][1];
+                lse_merge(m0, s0, xrow[1][t][0], xrow[1][t][1]);
+                p.rp_m[(int64_t)jt * B + i0 + t] = m0; p.rp_s[(int64_t)jt * B + i0 + t] = s0;
+            } else if (t < 2 * PT) { // columns: merge the four row tiles
+                const int jl = t - PT;
+                float m0 = xcol[0][jl][0], s0 = xcol[0][jl][1];
+                lse_merge(m0, s0, xcol[1][jl][0], xcol[1][jl][1]);
+                lse_merge(m0, s0, xcol[2][jl][0], xcol[2][jl][1]);
+                lse_merge(m0, s0, xcol[3][jl][0], xcol[3][jl][1]);
+                p.cp_m[(int64_t)it * B + j0 + jl] = m0; p.cp_s[(int64_t)it * B + j0 + jl] = s0;
+            }
+            continue;
+        }
+        // gradient modes: P = f(S) as a bf16 hi / lo pair in LDS, row-major [i][j]
+        f32x4 pv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 colc = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == PM_CON_GRAD || MODE == PM_UNIF) colc = *(const f32x4*)(p.colv + j0 + 16 * (2 * wc + c) + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool dg = (it == jt) && (16 * wr + c16 == 16 * (2 * wc + c) + 4 * g + r);
+                const float s = sc[c][r];
+                float v;
+                if (MODE == PM_CON_GRAD) {
+                    const float l = s * p.inv_temp;
+                    v = p.coef_row * __expf(l - rowc) + p.coef_col * __expf(l - colc[r]) - (dg ? p.coef_diag : 0.f);
+                    scal += v * l;
+                } else if (MODE == PM_UNIF) {
+                    v = dg ? 0.f : __expf(-p.t * fmaxf(rowc + colc[r] - 2.f * s, 0.f));
+                    rsum += v;
+                } else {
+                    v = s - (dg ? 1.f : -1.f);
+                    scal += v * v;
+                }
+                pv[c][r] = v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float r0, r1, r2, r3;
+            uint2 h, l;
+            h.x = pack_hi(pv[c][0], pv[c][1], r0, r1); h.y = pack_hi(pv[c][2], pv[c][3], r2, r3);
+            l.x = pack2(r0, r1); l.y = pack2(r2, r3);
+            const int po = (16 * wr + c16) * LDP + 16 * (2 * wc + c) + 4 * g;
+            *(uint2*)(Ph + po) = h; *(uint2*)(Pl + po) = l;
+        }
+        __syncthreads();                                       // P complete
+        // ---- second product: O'[e][i] += Z^T[e][j] P[i][j]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int ao = (16 * a + c16) * LDP + 32 * ks + 8 * g;
+                const bf16x8 ph = *(const bf16x8*)(Ph + ao), pl = *(const bf16x8*)(Pl + ao);
+#pragma unroll
+                for (int n = 0; n < NT2; ++n) {
+                    const bf16x8 zh = ks == 0 ? zh0[n] : zh1[n], zl = ks == 0 ? zl0[n] : zl1[n];
+                    oacc[a][n] = PMFMA(zh, ph, oacc[a][n]);
+                    oacc[a][n] = PMFMA(zl, ph, oacc[a][n]);
+                    oacc[a][n] = PMFMA(zh, pl, oacc[a][n]);
+                }
+            }
+        }
+    }
+    if (!GRAD) return;
+    // ---- outputs of the sweep: O partial, row-sum partial, scalar partial
+    float* od = p.opart + ((int64_t)split * B + i0) * E + wave * EC;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) *(f32x4*)(od + (int64_t)(16 * a + c16) * E + 16 * n + 4 * g) = oacc[a][n];   // lane: row i = 16 a + c16, columns 16 n + 4 g ..
+    if (MODE == PM_UNIF) {
+        rsum += __shfl_xor(rsum, 16, 64);
+        rsum += __shfl_xor(rsum, 32, 64);
+        __syncthreads();
+        if (g == 0) xrow[wc][16 * wr + c16][0] = rsum;
+        __syncthreads();
+        if (t < PT) p.spart[(int64_t)split * B + i0 + t] = xrow[0][t][0] + xrow[1][t][0];
+    } else {
+        scal = wave_sum(scal);
+        __syncthreads();
+        if (lane == 0) xred[wave] = scal;
+        __syncthreads();
+        if (t == 0) p.scal_part[it * p.nsplit + split] = ((xred[0] + xred[1]) + (xred[2] + xred[3])) + ((xred[4] + xred[5]) + (xred[6] + xred[7]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ finalisation kernels
+// LSE over the partials of one row / column: out[i] = log sum_k s_k exp(m_k)
+__global__ __launch_bounds__(256) void lse_final_kernel(const float* pm, const float* ps, int parts, int B, float* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    float m = -INFINITY;
+    for (int k = 0; k < parts; ++k) m = fmaxf(m, pm[(int64_t)k * B + i]);
+    float s = 0.f;
+    for (int k = 0; k < parts; ++k) {
+        const float mk = pm[(int64_t)k * B + i];
+        if (mk > -INFINITY) s += ps[(int64_t)k * B + i] * __expf(mk - m);
+    }
+    out[i] = m + logf(s);
+}
+// out = scale * sum_s part[s]   (fixed order), n elements
+__global__ __launch_bounds__(256) void sum_splits_kernel(const float* part, int nsplit, int64_t n, float scale, float* out) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    f32x4 s = *(const f32x4*)(part + i4);
+    for (int k = 1; k < nsplit; ++k) s += *(const f32x4*)(part + (int64_t)k * n + i4);
+    *(f32x4*)(out + i4) = s * scale;
+}
+// scalar: out[0] = scale * sum of n floats (one block, fixed order)
+__global__ __launch_bounds__(256) void sum_scalar_kernel(const float* part, int n, float scale, float* out) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * scale;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side (called from loss_head.hip)
+struct PairWs {      // carved from the caller's workspace
+    bf16_t *xh, *xl, *yh, *yl, *xth, *xtl, *yth, *ytl;
+    float *opart, *rp_m, *rp_s, *cp_m, *cp_s, *spart, *scal_part;
+};
+
+static int pair_nsplit(int64_t b) {
+    const int64_t it = b / PT;
+    int64_t s = 256 / it;
+    if (s < 1) s = 1;
+    if (s > it) s = it;
+    return (int)s;
+}
+
+size_t sc_pair_workspace_bytes(int64_t b, int64_t e) {
+    const int64_t it = b / PT, ns = pair_nsplit(b);
+    size_t n = 0;
+    auto add = [&](size_t bytes) { n += ((bytes + 255) / 256) * 256; };
+    for (int k = 0; k < 8; ++k) add((size_t)b * e * 2);
+    add((size_t)ns * b * e * 4);
+    for (int k = 0; k < 4; ++k) add((size_t)it * b * 4);
+    add((size_t)ns * b * 4);
+    add((size_t)it * ns * 4 + 64);
+    return n;
+}
+
+static void pair_carve(void* ws, int64_t b, int64_t e, PairWs& w) {
+    const int64_t it = b / PT, ns = pair_nsplit(b);
+    char* c = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = c; c += ((bytes + 255) / 256) * 256; return r; };
+    bf16_t** hs[8] = {&w.xh, &w.xl, &w.yh, &w.yl, &w.xth, &w.xtl, &w.yth, &w.ytl};
+    for (auto h : hs) *h = (bf16_t*)take((size_t)b * e * 2);
+    w.opart = (float*)take((size_t)ns * b * e * 4);
+    w.rp_m = (float*)take((size_t)it * b * 4); w.rp_s = (float*)take((size_t)it * b * 4);
+    w.cp_m = (float*)take((size_t)it * b * 4); w.cp_s = (float*)take((size_t)it * b * 4);
+    w.spart = (float*)take((size_t)ns * b * 4);
+    w.scal_part = (float*)take((size_t)it * ns * 4 + 64);
+}
+
+bool sc_pair_supported(int64_t b, int64_t e) { return b >= 2 * PT && b % PT == 0 && e % 128 == 0 && e >= 128 && e <= 1024 && b <= 65536; }
+
+template <int MODE>
+static int pair_launch(const PairParams& p, hipStream_t st) {
+    const dim3 grid((unsigned)(p.B / PT), (unsigned)p.nsplit);
+    switch (p.E / 128) {
+#define CASE(N) case N: hipLaunchKernelGGL((pair_kernel<MODE, N>), grid, dim3(512), 0, st, p); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        default: return sc_set_error(SC_ERR_SHAPE, "pairwise kernel: unsupported width %d", p.E);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+static void split_launch(const float* x, int64_t b, int64_t e, bf16_t* hi, bf16_t* lo, bf16_t* hi_t, bf16_t* lo_t, hipStream_t st) {
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)sc_cdiv(e, 32), (unsigned)sc_cdiv(b, 32)), dim3(256), 0, st, x, (int)b, (int)e, hi, lo, hi_t, lo_t);
+}
+
+// contrastive: row / column LSE + diagonal into rowv / colv / diag ([B] each); with d_img: both gradients and, if dtemp_part, the
+// partial sums of G v (count returned in *n_dtemp)
+int sc_pair_contrastive(const float* img, const float* txt, int64_t b, int64_t e, float inv_temp, float grad_scale, float* rowv, float* colv, float* diag,
+                        float* d_img, float* d_txt, float** dtemp_part, int* n_dtemp, void* ws, hipStream_t st) {
+    PairWs w;
+    pair_carve(ws, b, e, w);
+    const bool grad = d_img != nullptr;
+    split_launch(img, b, e, w.xh, w.xl, grad ? w.xth : nullptr, grad ? w.xtl : nullptr, st);
+    split_launch(txt, b, e, w.yh, w.yl, grad ? w.yth : nullptr, grad ? w.ytl : nullptr, st);
+    PairParams p = {};
+    p.xh = w.xh; p.xl = w.xl; p.yh = w.yh; p.yl = w.yl; p.B = (int)b; p.E = (int)e; p.inv_temp = inv_temp;
+    p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
+    p.rp_m = w.rp_m; p.rp_s = w.rp_s; p.cp_m = w.cp_m; p.cp_s = w.cp_s; p.diag = diag;
+    SC_TRY(pair_launch<PM_CON_STATS>(p, st));
+    const int parts = (int)(b / PT);
+    hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, 256)), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)b, rowv);
+    hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, 256)), dim3(256), 0, st, w.cp_m, w.cp_s, parts, (int)b, colv);
+    SC_CHECK_LAUNCH();
+    if (!grad) return SC_OK;
+    // G = gs [ (exp(L - r_i) + exp(L - c_j)) / (2B) - delta_ij / B ];  dI = G T / temp,  dT = G^T I / temp
+    p.coef_row = p.coef_col = grad_scale / (2.f * (float)b); p.coef_diag = grad_scale / (float)b;
+    p.opart = w.opart; p.scal_part = w.scal_part;
+    const int64_t n = b * e;
+    const unsigned rb = (unsigned)sc_cdiv(n / 4, 256);
+    p.rowv = rowv; p.colv = colv; p.zth = w.yth; p.ztl = w.ytl;                     // rows = images, columns = texts, Z = T
+    SC_TRY(pair_launch<PM_CON_GRAD>(p, st));
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(rb), dim3(256), 0, st, w.opart, p.nsplit, n, inv_temp, d_img);
+    if (dtemp_part) {   // sum G v, taken from the first sweep: hand the partials over before the second sweep overwrites them
+        float* keep = w.spart;   // free in the contrastive term
+        hipLaunchKernelGGL(sum_scalar_kernel, dim3(1), dim3(256), 0, st, w.scal_part, (int)(b / PT) * p.nsplit, 1.f, keep);
+        *dtemp_part = keep; *n_dtemp = 1;
+    }
+    PairParams q = p;                                                                // transposed problem: rows = texts
+    q.xh = w.yh; q.xl = w.yl; q.yh = w.xh; q.yl = w.xl; q.rowv = colv; q.colv = rowv; q.zth = w.xth; q.ztl = w.xtl;
+    SC_TRY(pair_launch<PM_CON_GRAD>(q, st));
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(rb), dim3(256), 0, st, w.opart, p.nsplit, n, inv_temp, d_txt);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+// lunif: W = exp(-t max(|xi|^2 + |xj|^2 - 2 xi.xj, 0)) off the diagonal: row sums s_i -> rowsum[B], W X -> wx[B,E] (both final)
+int sc_pair_lunif(const float* x, const float* sumsq, int64_t b, int64_t e, float t, float* rowsum, float* wx, void* ws, hipStream_t st) {
+    PairWs w;
+    pair_carve(ws, b, e, w);
+    split_launch(x, b, e, w.xh, w.xl, w.xth, w.xtl, st);
+    PairParams p = {};
+    p.xh = w.xh; p.xl = w.xl; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.B = (int)b; p.E = (int)e; p.t = t;
+    p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
+    p.rowv = sumsq; p.colv = sumsq; p.opart = w.opart; p.spart = w.spart; p.scal_part = w.scal_part;
+    SC_TRY(pair_launch<PM_UNIF>(p, st));
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)sc_cdiv(b * e / 4, 256)), dim3(256), 0, st, w.opart, p.nsplit, b * e, 1.f, wx);
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)sc_cdiv(b / 4, 256)), dim3(256), 0, st, w.spart, p.nsplit, b, 1.f, rowsum);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+// sparsify_loss: D = X X^T - (2I - 1): loss_out[0] = mean D^2, dx = grad_scale * 4 / B^2 * D X (dx may be null)
+int sc_pair_sparsify(const float* x, int64_t b, int64_t e, float grad_scale, float* loss_out, float* dx, float* scratch_be, void* ws, hipStream_t st) {
+    PairWs w;
+    pair_carve(ws, b, e, w);
+    split_launch(x, b, e, w.xh, w.xl, w.xth, w.xtl, st);
+    PairParams p = {};
+    p.xh = w.xh; p.xl = w.xl; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.B = (int)b; p.E = (int)e;
+    p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
+    p.opart = w.opart; p.scal_part = w.scal_part;
+    SC_TRY(pair_launch<PM_SPARS>(p, st));
+    const float inv = 1.0f / ((float)b * (float)b);
+    hipLaunchKernelGGL(sum_scalar_kernel, dim3(1), dim3(256), 0, st, w.scal_part, (int)(b / PT) * p.nsplit, inv, loss_out);
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)sc_cdiv(b * e / 4, 256)), dim3(256), 0, st, w.opart, p.nsplit, b * e, dx ? grad_scale * 4.0f * inv : 0.f,
+                       dx ? dx : scratch_be);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
