@@ -16,6 +16,7 @@
 // f(S) is written to LDS as a bf16 hi/lo pair (the A operand of the second product); O[64,E] += P[64,64] Z_j[64,E] with every wave
 // owning E/8 output columns and reading its rows of Z^T (a [E,B] copy made once per call) straight from global memory.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -351,7 +352,8 @@ struct PairWs {      // carved from the caller's workspace
 
 static int pair_nsplit(int64_t b) {
     const int64_t it = b / PT;
-    int64_t s = 256 / it;
+    static const int wgs = [] { const char* e = getenv("SC_PAIR_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // two workgroups per CU hide each other's barriers
+    int64_t s = wgs / it;
     if (s < 1) s = 1;
     if (s > it) s = it;
     return (int)s;
