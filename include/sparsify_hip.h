@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_SHAPE = -2, SC_ERR_DTYPE = -3, SC_ERR_ALIGN = -4,
        SC_ERR_WORKSPACE = -5, SC_ERR_NO_DEVICE = -6 };
@@ -63,6 +63,12 @@ typedef struct sc_gemm_epilogue {
     uint64_t colsum_ws_bytes;
     int32_t colsum_accumulate;
     int32_t reserved_;
+    /* optional, sc_gemm_bf16_nt only: 64 bytes of device memory, 64-byte aligned, ZERO when first used, owned by the caller and
+     * used by the GEMM calls of ONE stream at a time.  With it the persistent kernel's workgroups claim their 256x256 tiles from
+     * per-XCD ticket counters instead of walking fixed lists, so a launch that shares the GPU with other kernels (another stream,
+     * an RCCL collective) finishes when the work is done rather than when the most delayed workgroup has walked its list.  The
+     * kernel leaves the words zero again when it ends; the result does not depend on which workgroup computed which tile. */
+    void* tile_tickets;
 } sc_gemm_epilogue;
 
 /* fp32 MFMA GEMM, any operand orientation: C[M,N] = op(A) * op(B).
@@ -245,6 +251,9 @@ typedef struct sc_block_desc {
      * call.  The library keeps none of its own: descriptors used from different host threads or devices get different events;
      * descriptors enqueued one after the other from ONE thread may share a set. */
     void* events[4];
+    /* optional: tile tickets for the NT GEMMs the call enqueues on `stream` (sc_gemm_epilogue.tile_tickets: 64 zeroed, 64-byte
+     * aligned bytes); descriptors whose calls are enqueued on one stream may share them.  NULL = fixed tile lists. */
+    void* tile_tickets;
 } sc_block_desc;
 
 size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype);

@@ -5,7 +5,10 @@ flight between an inline `ds_read*` and the hand-placed `s_waitcnt lgkmcnt(0)`. 
 fails the build if, inside one of those kernels,
   * the compiler itself touches an AGPR (v_accvgpr_write with a register source, v_accvgpr_mov) - it would be using the
     accumulators as spill space - or the kernel needs scratch;
-  * any instruction other than an MFMA or another LDS read names a VGPR that is the destination of an LDS read still in flight.
+  * any instruction other than an MFMA or another LDS read names a VGPR that is the destination of an LDS read still in flight;
+  * any compiler-generated instruction names the VGPR an inline-asm returning atomic (the persistent kernel's tile ticket) is
+    writing, between that atomic and the next inline-asm `s_waitcnt vmcnt(0)` in layout order (the two sit in one straight trip
+    of the K loop).
 """
 from __future__ import annotations
 
@@ -61,6 +64,9 @@ def audit(asm_text: str):
         if not any(k in name for k in KERNELS) or ".Lfunc_end" not in chunk:
             continue
         ins = _parse(chunk[: chunk.index(".Lfunc_end")])
+        # the stamped (STAMP = true) instances of the persistent kernel are measurement builds (tools/gemm_stamps.py): a spilled
+        # time stamp there is tolerated, everything else is checked as in the production instances
+        diagnostic = "gemm_bf16_nt_pers_kernel" in name and "ELb1E" in name
         # basic blocks
         starts = {0}
         label_at = {}
@@ -87,7 +93,7 @@ def audit(asm_text: str):
                 if lab:
                     continue
                 last_op = op
-                if op.startswith("scratch_") and report:
+                if op.startswith("scratch_") and report and not diagnostic:
                     problems.append(f"{name}: scratch access `{text}`")
                 if not in_asm and op.startswith("v_accvgpr") and report:
                     problems.append(f"{name}: compiler-generated AGPR traffic `{text}`")
@@ -130,6 +136,24 @@ def audit(asm_text: str):
             for r in list(a[0]) + list(b_[0]):
                 loose |= r
             return ((), frozenset(loose), a[2] or b_[2])
+
+        # the ticket register: linear scan (layout order)
+        pending = set()
+        for lab, op, toks, text, in_asm in ins:
+            if lab:
+                continue
+            if in_asm and op.startswith("global_atomic") and "sc0" in toks:
+                pending = set(_regs(toks[0]))
+                continue
+            if in_asm and op == "s_waitcnt" and "vmcnt(0)" in text:
+                pending = set()
+                continue
+            if pending and not in_asm:
+                used = set()
+                for x in toks:
+                    used |= _regs(x)
+                if used & pending:
+                    problems.append(f"{name}: `{text}` touches VGPRs {sorted(used & pending)} that an inline-asm atomic is still writing")
 
         state_in = {b: None for b in order}
         state_in[order[0]] = ((), frozenset(), False)

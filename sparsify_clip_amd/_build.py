@@ -59,7 +59,11 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         gemm = os.path.join(CSRC, "gemm_bf16.hip")
         if any(gemm in cmd for cmd in jobs):   # the kernels with hand-managed AGPRs / in-flight LDS reads are audited whenever they are rebuilt
             from ._asm_check import check
-            check(HIPCC, gemm, [f for f in FLAGS if f != "-fPIC"])
+            try:
+                check(HIPCC, gemm, [f for f in FLAGS if f != "-fPIC"])
+            except Exception:
+                os.remove(os.path.join(OBJ, os.path.basename(gemm) + ".o"))   # a failed audit must not leave an object the next build would link
+                raise
             if verbose:
                 print("asm audit of gemm_bf16.hip: ok", flush=True)
     if force or jobs or _newer(LIB, objs):

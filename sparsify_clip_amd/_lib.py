@@ -27,7 +27,7 @@ class GemmEpilogue(ctypes.Structure):
                 ("act", ctypes.c_int32), ("resid_dtype", ctypes.c_int32), ("resid", ctypes.c_void_p),
                 ("dgelu_pre", ctypes.c_void_p), ("ld_aux", ctypes.c_int64),
                 ("colsum", ctypes.c_void_p), ("colsum_ws", ctypes.c_void_p), ("colsum_ws_bytes", ctypes.c_uint64),
-                ("colsum_accumulate", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+                ("colsum_accumulate", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("tile_tickets", ctypes.c_void_p)]
 
 
 _BLOCK_PTRS_1 = ["ln1_g", "ln1_b", "b_qkv", "b_o", "ln2_g", "ln2_b", "b_fc1", "b_fc2",
@@ -46,7 +46,7 @@ class BlockDesc(ctypes.Structure):
                 [("accumulate", ctypes.c_int32), ("b_fc2_done", ctypes.c_int32)] +
                 [(n, ctypes.c_void_p) for n in _BLOCK_PTRS_2] +
                 [("ws_bytes", ctypes.c_size_t), ("g_below_b_fc2", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_size_t),
-                 ("events", ctypes.c_void_p * 4)])
+                 ("events", ctypes.c_void_p * 4), ("tile_tickets", ctypes.c_void_p)])
 
 
 _CTYPES = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,

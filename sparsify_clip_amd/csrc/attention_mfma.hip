@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
         if (cs_part) cs_add(csq, dq, i < S);
     }
     __syncthreads();   // the row statistics of BOTH waves' query tiles are in LDS
-    // statistics rows of the padding tile (only read when NT is odd and the last k-step is half empty: never) stay untouched
+    // (statistics exist for the query tiles below n_t only: pass 2 skips the others)
     // ---------------- pass 2: lane = key row j.  P^T, dS^T products -> dV, dK
     for (int jt = half; jt < n_t; jt += WPH) {
         const bf16x8 k0 = row_frag_lds(Ks, jt, 0, lane), k1 = row_frag_lds(Ks, jt, 1, lane);
@@ -247,8 +247,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
             for (int u = 0; u < 2; ++u) {
                 pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int it = 2 * s + u;
-                if (ODD && it >= NT) continue;
-                if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0   // compile-time: the empty half of the last k-step
+                if (ODD && it >= NT) continue;      // compile-time: the empty half of the last k-step
+                if (it >= n_t) continue;            // query tile beyond the sequence (S <= 16 (NT - 1)): pass 1 wrote no statistics for it
+                if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0
                 f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
                 a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
                 a = MFMA16(row_frag_lds(Qs, it, 1, lane), k1, a);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
                     const bool ok = i < S && j < S && (!CAUSAL || j <= i);
                     const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
                     pt[u][r] = p;
-                    dst[u][r] = p * (d[r] - dl[r]) * scale;
+                    dst[u][r] = ok ? p * (d[r] - dl[r]) * scale : 0.f;   // not 0 * (d - dl): d, dl of a masked pair need not be finite
                 }
             }
             if (CAUSAL && 2 * s + 1 < jt) continue;

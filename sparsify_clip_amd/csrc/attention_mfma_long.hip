@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
                 pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int it = 2 * s + u;
                 if (ODD && it >= NT) continue;
+                if (it >= n_t) continue;            // query tile beyond the sequence: pass 1 wrote no statistics for it
                 if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0
                 f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
                 a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
                     const bool ok = i < S && j < S && (!CAUSAL || j <= i);
                     const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
                     pt[u][r] = p;
-                    dst[u][r] = p * (d[r] - dl[r]) * scale;
+                    dst[u][r] = ok ? p * (d[r] - dl[r]) * scale : 0.f;   // not 0 * (d - dl): d, dl of a masked pair need not be finite
                 }
             }
             if (CAUSAL && 2 * s + 1 < jt) continue;
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const b
                 pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int it = 2 * s + u;
                 if (ODD && it >= NT) continue;
+                if (it >= n_t) continue;            // query tile beyond the sequence: pass 1 wrote no statistics for it
                 if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0
                 f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
                 a = MFMA16(row_frag_lds(Qs, it, 0, lane), k0, a);
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const b
                     const bool ok = i < S && j < S && (!CAUSAL || j <= i);
                     const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
                     pt[u][r] = p;
-                    dst[u][r] = p * (d[r] - dl[r]) * scale;
+                    dst[u][r] = ok ? p * (d[r] - dl[r]) * scale : 0.f;   // not 0 * (d - dl): d, dl of a masked pair need not be finite
                 }
             }
             if (CAUSAL && 2 * s + 1 < jt) continue;

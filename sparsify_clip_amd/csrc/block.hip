@@ -41,14 +41,22 @@ bool unfuse_gelu() {
 
 // y[rows,n] = x[rows,k] W[n,k]^T (+ epilogue); W in torch [out,in] layout
 int linear_fwd(int dtype, int64_t rows, int64_t n, int64_t k, const void* x, const void* w, void* y, int out_dtype, const EpiParams& epi,
-               hipStream_t st) {
-    if (dtype == SC_BF16) return sc_gemm_bf16_nt_launch(rows, n, k, x, k, w, k, y, n, out_dtype, epi, st);
+               hipStream_t st, void* tickets) {
+    if (dtype == SC_BF16) {
+        EpiParams e = epi;
+        e.tickets = (unsigned*)tickets;
+        return sc_gemm_bf16_nt_launch(rows, n, k, x, k, w, k, y, n, out_dtype, e, st);
+    }
     return sc_gemm_f32_launch(0, 1, rows, n, k, (const float*)x, k, (const float*)w, k, (float*)y, n, epi, st);
 }
 // dx[rows,k] = dy[rows,n] W[n,k]  (bf16: NT against the [in,out] copy wt[k,n])
 int linear_dx(int dtype, int64_t rows, int64_t n, int64_t k, const void* dy, const void* w, const void* wt, void* dx, const EpiParams& epi,
-              hipStream_t st) {
-    if (dtype == SC_BF16) return sc_gemm_bf16_nt_launch(rows, k, n, dy, n, wt, n, dx, k, SC_BF16, epi, st);
+              hipStream_t st, void* tickets) {
+    if (dtype == SC_BF16) {
+        EpiParams e = epi;
+        e.tickets = (unsigned*)tickets;
+        return sc_gemm_bf16_nt_launch(rows, k, n, dy, n, wt, n, dx, k, SC_BF16, e, st);
+    }
     return sc_gemm_f32_launch(0, 0, rows, k, n, (const float*)dy, n, (const float*)w, k, (float*)dx, k, epi, st);
 }
 // dw[n,k] (+)= dy[rows,n]^T x[rows,k]; bf16 with db != null: db[n] (+)= column sums of dy, fused into the same kernel (the
@@ -105,7 +113,7 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
     SC_TRY(sc_layernorm_fwd(d->x_in, rows, W, d->ln1_g, d->ln1_b, d->ln1_out, dt, d->ln1_mean, d->ln1_rstd, stream));
     EpiParams e = epi_plain();
     e.bias = d->b_qkv;
-    SC_TRY(linear_fwd(dt, rows, 3 * W, W, d->ln1_out, d->w_qkv, d->qkv, dt, e, st));
+    SC_TRY(linear_fwd(dt, rows, 3 * W, W, d->ln1_out, d->w_qkv, d->qkv, dt, e, st, d->tile_tickets));
     if (dt == SC_F32 && d->seq > 128)   // fp32 parity path of long sequences: composed from the fp32 GEMM, needs a workspace
         SC_TRY(sc_attention_f32_composed_fwd((const float*)d->qkv, (float*)d->attn_out, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, (hipStream_t)stream));
     else
@@ -113,22 +121,22 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
     // out_proj (+bias) + residual -> fp32 x_mid
     e = epi_plain();
     e.bias = d->b_o; e.resid = d->x_in; e.resid_dtype = SC_F32; e.ld_aux = W;
-    SC_TRY(linear_fwd(dt, rows, W, W, d->attn_out, d->w_o, d->x_mid, SC_F32, e, st));
+    SC_TRY(linear_fwd(dt, rows, W, W, d->attn_out, d->w_o, d->x_mid, SC_F32, e, st, d->tile_tickets));
     // ln_2 -> c_fc (+bias, keep pre-activation) -> GELU
     SC_TRY(sc_layernorm_fwd(d->x_mid, rows, W, d->ln2_g, d->ln2_b, d->ln2_out, dt, d->ln2_mean, d->ln2_rstd, stream));
     e = epi_plain();
     if (dt == SC_BF16 && unfuse_gelu()) {
         e.bias = d->b_fc1;
-        SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_pre, dt, e, st));
+        SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_pre, dt, e, st, d->tile_tickets));
         SC_TRY(sc_gelu_fwd_bf16(d->h_pre, d->h_act, rows * MLP, st));
     } else {
         e.bias = d->b_fc1; e.pre_out = d->h_pre; e.act = 1; e.ld_aux = MLP;
-        SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_act, dt, e, st));
+        SC_TRY(linear_fwd(dt, rows, MLP, W, d->ln2_out, d->w_fc1, d->h_act, dt, e, st, d->tile_tickets));
     }
     // c_proj (+bias) + residual -> fp32 x_out
     e = epi_plain();
     e.bias = d->b_fc2; e.resid = d->x_mid; e.resid_dtype = SC_F32; e.ld_aux = W;
-    SC_TRY(linear_fwd(dt, rows, W, MLP, d->h_act, d->w_fc2, d->x_out, SC_F32, e, st));
+    SC_TRY(linear_fwd(dt, rows, W, MLP, d->h_act, d->w_fc2, d->x_out, SC_F32, e, st, d->tile_tickets));
     return SC_OK;
 }
 
@@ -202,14 +210,14 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
             e.colsum = d->g_b_fc1; e.colsum_ws = d->ws; e.colsum_ws_bytes = d->ws_bytes; e.colsum_accumulate = acc;
         }
     }
-    SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st));                 // d_h = (dx_out W2) * gelu'(h_pre)
+    SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st, d->tile_tickets));                 // d_h = (dx_out W2) * gelu'(h_pre)
     if (ug) SC_TRY(sc_dgelu_mul_colsum_bf16(d->d_h, d->h_pre, rows, MLP, d->g_b_fc1, acc, d->ws, d->ws_bytes, st));
     if (!gate && !grouped) {
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, MLP, W, d->d_h, d->ln2_out, d->g_w_fc1, acc, wsw, wsw_bytes, ss));
         if (!fcs) SC_TRY(sc_colsum(d->d_h, dt, rows, MLP, MLP, d->g_b_fc1, acc, wsw, wsw_bytes, (void*)ss));
     }
-    SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st)); // d ln_2 output
+    SC_TRY(linear_dx(dt, rows, MLP, W, d->d_h, d->w_fc1, d->wt_fc1, d->d_ln, epi_plain(), st, d->tile_tickets)); // d ln_2 output
     // dx_mid = dx_out + LN2'(d_ln); the same kernel emits the operand copy and the out_proj bias gradient (column sums of dx_mid).
     // With a side stream the copy must not land in the buffer `g` that the side stream may still be reading (internal-cast case).
     SC_REQUIRE(!(two && bf && g == d->d_res_t), SC_ERR_ARG, "sc_block_bwd_async: pass dx_out_t (the internal cast reuses d_res_t)");
@@ -221,7 +229,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, W, W, gm, d->attn_out, d->g_w_o, acc, wsw, wsw_bytes, ss));
     }
-    SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st));
+    SC_TRY(linear_dx(dt, rows, W, W, gm, d->w_o, d->wt_o, d->d_attn, epi_plain(), st, d->tile_tickets));
     if (gate && !grouped) {   // everything the three GEMMs read (g, h_act, d_h, ln2_out, d_res_t, attn_out) is final here
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
@@ -245,7 +253,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
         SC_TRY(linear_dw(dt, rows, 3 * W, W, d->d_qkv, d->ln1_out, d->g_w_qkv, acc, wsw, wsw_bytes, ss));
     }
     if (!fcs) SC_TRY(sc_colsum(d->d_qkv, dt, rows, 3 * W, 3 * W, d->g_b_qkv, acc, wsw, wsw_bytes, (void*)ss));
-    SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st));
+    SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st, d->tile_tickets));
     // dx_in = dx_mid + LN1'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,
                             d->g_ln1_b, d->g_below_b_fc2, acc, d->ws, d->ws_bytes, stream));

@@ -748,6 +748,20 @@ struct NtpTile {   // one entry of a workgroup's tile list (wave-uniform; three 
     int m0, n0;
     int half;        // != 0: 128 x 256 instead of 256 x 256
 };
+// Ticket of the dynamic tile order (see gemm_bf16_nt_pers_kernel).  request: lane 0 of the calling wave adds 1 to *counter, the old
+// value arrives in `ret` about a microsecond later - written out so that nothing waits for it here (the compiler's own atomicAdd is
+// followed by s_waitcnt vmcnt(0) at once).  publish: called behind the NEXT K-tile's s_waitcnt vmcnt(0) (which the returned value
+// has shared with that K-tile's LDS-DMA), stores it to the LDS word `box`.  Between the two calls `ret` is a register with a
+// write in flight: the build-time audit fails if any instruction names it there.
+__device__ __forceinline__ void ntp_ticket_request(unsigned* counter, int& ret) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %0, 1\n\tglobal_atomic_add %0, %2, %0, %3 sc0\n\ts_mov_b64 exec, %1"
+                 : "=&v"(ret), "=&s"(saved) : "v"(0u), "s"(counter) : "memory");
+}
+__device__ __forceinline__ void ntp_ticket_publish(unsigned box, int ret) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(box), "v"(ret) : "memory");
+}
 
 // Tiles 0 .. full-1 are 256x256 (band / cell walk of the one-tile-per-workgroup kernel), tiles full .. full+half_tiles-1 are
 // 128x256 and cover the rows from half_m0 on: the launcher turns the last, partly filled round of 256x256 tiles into (at most
@@ -771,15 +785,34 @@ __device__ __forceinline__ NtpTile ntp_tile_of(const GemmBf16Params& p, int vb, 
     return t;
 }
 
+// The persistent kernel reads its arguments from the kernarg segment WHEN IT NEEDS THEM instead of holding ~35 of them in SGPRs for
+// the whole launch (the kernel sits at the 102-SGPR limit; what does not fit is kept in VGPR lanes and - for the LDS-DMA bases -
+// in VGPRs, with v_readfirstlane in front of every use).  ntp_args launders the segment pointer, so loads behind it cannot be
+// merged with loads in front of it: called at the start of a tile, in front of the next-tile computation and in front of the
+// epilogue, each phase loads its own few arguments (scalar loads that hit the constant cache) and nothing else is live across it.
+typedef const __attribute__((address_space(4))) GemmBf16Params* ntp_kargs_t;
+__device__ __forceinline__ const GemmBf16Params& ntp_args() {
+    ntp_kargs_t k = (ntp_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();   // the parameter struct is the first (only) explicit argument
+    asm volatile("" : "+s"(k));
+    return *(const GemmBf16Params*)k;
+}
+// wave-uniform by construction; said explicitly, so that the value is in SGPRs whatever the optimiser made of the tile walk (at
+// the SGPR limit it keeps uniform values in VGPRs, which an "s" operand of inline assembly does not survive)
+__device__ __forceinline__ const char* ntp_uniform(const char* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
 // LDS-DMA of K-tile KT of tile `t` into stage S.  Full tile: wave w brings A rows 32 w .. 32 w + 31 (4 instructions) and the same B
 // rows; half tile: A rows 16 w .. 16 w + 15 (2 instructions, the per-lane offsets of a full tile against a base moved back by 16 w rows).
 __device__ __forceinline__ void ntp_stage(const GemmBf16Params& p, const NtpTile& t, int stage, int kt, unsigned lds0, int wave, const unsigned (&oa)[4],
                                           const unsigned (&ob)[4]) {
     const unsigned la = lds0 + stage * B_STAGE + (wave * 32) * 128;
-    const char* ak = (const char*)p.A + ((int64_t)t.m0 * p.lda + kt * KSTEP) * 2;
-    const char* bk = (const char*)p.B + ((int64_t)t.n0 * p.ldb + kt * KSTEP) * 2;
+    // leading dimensions: 32-bit (the launcher admits ld < 2^22 only) - the kernel sits at the SGPR limit
+    const char* ak = ntp_uniform((const char*)p.A + ((int64_t)t.m0 * (int)p.lda + kt * KSTEP) * 2);
+    const char* bk = ntp_uniform((const char*)p.B + ((int64_t)t.n0 * (int)p.ldb + kt * KSTEP) * 2);
     if (t.half) {
-        const char* akh = ak - (int64_t)(wave * 16) * p.lda * 2;
+        const char* akh = ak - (int64_t)(wave * 16) * (int)p.lda * 2;
         const unsigned lah = lds0 + stage * B_STAGE + (wave * 16) * 128;
         glds16_saddr(akh, oa[0], lah);
         glds16_saddr(akh, oa[1], lah + 1024);
@@ -794,25 +827,31 @@ __device__ __forceinline__ void ntp_stage(const GemmBf16Params& p, const NtpTile
 // One tile: main loop on the stages requested earlier, request of the next tile's first two K-tiles between the two sub-steps of the
 // last K-tile, epilogue.  HALF: wave (wm, wn) owns rows 64 wm .. 64 wm + 63 (4 MFMA row tiles, accumulators a0 .. a63).
 template <int EPI, bool HALF, bool STAMP>
-__device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem, unsigned lds0, int lane, int wave, const NtpTile& cur, const NtpTile& nxt,
-                                             bool more, bool first, const unsigned (&oa)[4], const unsigned (&ob)[4], int vb) {
+__device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane, int wave, int nk, const NtpTile& cur,
+                                             bool first, const unsigned (&oa)[4], const unsigned (&ob)[4], int vb, unsigned* tickets, NtpTile& nxt, bool& more,
+                                             int& vn) {
     constexpr int NG = HALF ? 4 : 8;
     constexpr bool OUT_F32 = EPI == NTP_RESID;
     const int wm = wave >> 2, wn = wave & 3;
-    const int nk = p.K / KSTEP;
+    const GemmBf16Params& p = ntp_args();   // main loop and tile walk: A, B, lda, ldb, tiles_*, group_*, half_*
     bf16x8 a[8], b0[4], b1[4];
     const int frow = lane & 15, fq = lane >> 4;
     const unsigned pos0 = ((fq) ^ (lane & 7)) * 16, pos1 = ((4 + fq) ^ (lane & 7)) * 16;
     const unsigned fa = lds0 + (wm * (HALF ? 64 : 128) + frow) * 128, fb = lds0 + B_A + (wn * 64 + frow) * 128;
     const unsigned fa00 = fa + pos0, fa01 = fa + pos1, fa10 = fa + B_STAGE + pos0, fa11 = fa + B_STAGE + pos1;
     const unsigned fb00 = fb + pos0, fb01 = fb + pos1, fb10 = fb + B_STAGE + pos0, fb11 = fb + B_STAGE + pos1;
-#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0)   /* K-tile KT is not the last one: as NTB_FULL */    \
+    // dynamic tile order: wave 0 requests the next tile's ticket with the LDS-DMA of K-tile 0 and publishes it behind K-tile 1's wait
+    // (the two K-tiles of one trip of the loop below, so the register is not carried around the loop); nk >= 3, checked by the launcher
+    const unsigned box = lds0 + 2 * B_STAGE;
+#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0, HOOK)   /* K-tile KT is not the last one: as NTB_FULL */    \
     do {                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
         ntb_substep<0, true, false, NG>(a, b0, b1, A_S1, B_S1);                                       \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        if ((HOOK) && (S) == 1 && tickets && wave == 0 && (KT) == 1) ntp_ticket_publish(box, ticket); \
         __builtin_amdgcn_s_barrier();                                                                 \
         if ((KT) + 2 < nk) ntp_stage(p, cur, S, (KT) + 2, lds0, wave, oa, ob);                    \
+        if ((HOOK) && (S) == 0 && tickets && wave == 0 && (KT) == 0) ntp_ticket_request(tickets, ticket); \
         ntb_substep<0, true, false, NG>(a, b1, b0, A_N0, B_N0);                                       \
     } while (0)
     ntb_zero<0>();
@@ -832,17 +871,36 @@ __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem
     }
     int kt = 0;
     for (; kt + 2 < nk; kt += 2) {
-        NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
-        NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00);
+        int ticket;
+        NTP_FULL(0, kt, fa01, fb01, fa10, fb10, 1);
+        NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00, 1);
     }
     const bool two_left = kt + 1 < nk;
-    if (two_left) NTP_FULL(0, kt, fa01, fb01, fa10, fb10);
+    if (two_left) {
+        int ticket = 0;   // kt > 0 here: no ticket traffic in this K-tile
+        NTP_FULL(0, kt, fa01, fb01, fa10, fb10, 0);
+        (void)ticket;
+    }
     // last K-tile: sub-step 0 under the reads of sub-step 1; then every read of both stages has retired on every wave (barrier),
     // so the next tile's first two K-tiles are requested here, under the last MFMAs and the epilogue
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     ntb_substep<0, true, false, NG>(a, b0, b1, two_left ? fa11 : fa01, two_left ? fb11 : fb01);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // the next tile: workgroup b's static list (b, b + G, ...) or, dynamic order, the ticket wave 0 published in front of this K-tile
+    // (XCD x draws tile 8 k + x)
+    vn = tickets ? __builtin_amdgcn_readfirstlane(*(const int*)(smem + 2 * B_STAGE)) * 8 + (int)(blockIdx.x & 7) : vb + (int)gridDim.x;
+    more = vn < p.tiles_m * p.tiles_n + p.half_tiles;
+    if (more) nxt = ntp_tile_of(p, vn, p.tiles_m * p.tiles_n);
+    if (tickets) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave has read the word before wave 0's epilogue may overwrite it (it lives in its slab)
+    }
+    const GemmBf16Params& pe = ntp_args();   // the epilogue's arguments (C, ldc, bias, aux pointers): requested here, under the last MFMAs
+    const EpiParams& e = pe.epi;
+    const float* const e_bias = e.bias;
+    char* const e_c = (char*)pe.C;
+    const int e_ldc = (int)pe.ldc;
     if (more) {
         ntp_stage(p, nxt, 0, 0, lds0, wave, oa, ob);
         if (nk > 1) ntp_stage(p, nxt, 1, 1, lds0, wave, oa, ob);
@@ -854,34 +912,33 @@ __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem
 
     // ---- epilogue of the tile
     {
-        const EpiParams& e = p.epi;
         const int erow = lane >> 3, ecol = (lane & 7) * 8;
         const int mw = cur.m0 + wm * (HALF ? 64 : 128), nw = cur.n0 + wn * 64;
         NtpEpi c;
         constexpr int ES = OUT_F32 ? 4 : 2;
-        c.row_bytes_c = (unsigned)(p.ldc * ES);
-        c.c = (char*)p.C + ((int64_t)mw * p.ldc + nw) * ES;
-        c.voff_c = (unsigned)((erow * (int)p.ldc + ecol) * ES);
+        c.row_bytes_c = (unsigned)(e_ldc * ES);
+        c.c = e_c + ((int64_t)mw * e_ldc + nw) * ES;
+        c.voff_c = (unsigned)((erow * e_ldc + ecol) * ES);
         c.aux = nullptr; c.pre = nullptr; c.row_bytes_aux = c.row_bytes_pre = 0; c.voff_aux = c.voff_pre = 0;
         if constexpr (EPI == NTP_DGELU) {
-            c.row_bytes_aux = (unsigned)(e.ld_aux * 2);
-            c.aux = (const char*)e.dgelu_pre + ((int64_t)mw * e.ld_aux + nw) * 2;
-            c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
+            c.row_bytes_aux = (unsigned)(e_ldc * 2);
+            c.aux = (const char*)e.dgelu_pre + ((int64_t)mw * e_ldc + nw) * 2;
+            c.voff_aux = (unsigned)((erow * e_ldc + ecol) * 2);
         }
         if constexpr (EPI == NTP_RESID) {
-            c.row_bytes_aux = (unsigned)(e.ld_aux * 4);
-            c.aux = (const char*)e.resid + ((int64_t)mw * e.ld_aux + nw) * 4;
-            c.voff_aux = (unsigned)((erow * (int)e.ld_aux + ecol) * 4);
+            c.row_bytes_aux = (unsigned)(e_ldc * 4);
+            c.aux = (const char*)e.resid + ((int64_t)mw * e_ldc + nw) * 4;
+            c.voff_aux = (unsigned)((erow * e_ldc + ecol) * 4);
         }
         if constexpr (EPI == NTP_GELU_PRE) {
-            c.row_bytes_pre = (unsigned)(e.ld_aux * 2);
-            c.pre = (char*)e.pre_out + ((int64_t)mw * e.ld_aux + nw) * 2;
-            c.voff_pre = (unsigned)((erow * (int)e.ld_aux + ecol) * 2);
+            c.row_bytes_pre = (unsigned)(e_ldc * 2);
+            c.pre = (char*)e.pre_out + ((int64_t)mw * e_ldc + nw) * 2;
+            c.voff_pre = (unsigned)((erow * e_ldc + ecol) * 2);
         }
         c.slab = smem + 2 * B_STAGE + wave * P_SLAB;
         c.slab_wr = smem + 2 * B_STAGE + wave * P_SLAB + frow * 256;
         c.bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; c.bias1 = c.bias0;
-        if (e.bias) { c.bias0 = *(const f32x4*)(e.bias + nw + ecol); c.bias1 = *(const f32x4*)(e.bias + nw + ecol + 4); }
+        if (e_bias) { c.bias0 = *(const f32x4*)(e_bias + nw + ecol); c.bias1 = *(const f32x4*)(e_bias + nw + ecol + 4); }
         const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;
         f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
         NtpAux<EPI> x0;
@@ -896,8 +953,8 @@ __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem
                     cs0[j] += __shfl_xor(cs0[j], 32, 64); cs1[j] += __shfl_xor(cs1[j], 32, 64);
                 }
                 if (lane < 8) {   // partial rows: one per 128 output rows for full tiles, one per 64 rows for half tiles (the rows after them)
-                    const int64_t slot = HALF ? (int64_t)(p.half_m0 / 128) + (mw - p.half_m0) / 64 : (int64_t)(mw / 128);
-                    float* dst = e.cs_partial + slot * p.N + nw + ecol;
+                    const int64_t slot = HALF ? (int64_t)(pe.half_m0 / 128) + (mw - pe.half_m0) / 64 : (int64_t)(mw / 128);
+                    float* dst = e.cs_partial + slot * pe.N + nw + ecol;
                     *(f32x4*)dst = cs0;
                     *(f32x4*)(dst + 4) = cs1;
                 }
@@ -916,11 +973,11 @@ __device__ __forceinline__ void ntp_run_tile(const GemmBf16Params& p, char* smem
 // STAMP = true is a DIAGNOSTIC instance (tools/gemm_stamps.py): wave 0 records s_memtime at the start of a tile's main loop, at its
 // end, and at the end of the epilogue into p.stamps (a buffer nothing else reads); the production instances contain no stamp.
 template <int EPI, bool STAMP = false>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Params p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Params) {   // read through ntp_args, see there
     __shared__ __attribute__((aligned(1024))) char smem[P_LDS];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int full = p.tiles_m * p.tiles_n, ntiles = full + p.half_tiles;
+    const GemmBf16Params& p = ntp_args();
     const int nk = p.K / KSTEP;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
 
@@ -932,26 +989,50 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
         const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            oa[q] = (unsigned)(((wave * 32 + q * 8 + srow) * p.lda + schunk * 8) * 2);
-            ob[q] = (unsigned)(((wave * 32 + q * 8 + srow) * p.ldb + schunk * 8) * 2);
+            oa[q] = (unsigned)(((wave * 32 + q * 8 + srow) * (int)p.lda + schunk * 8) * 2);
+            ob[q] = (unsigned)(((wave * 32 + q * 8 + srow) * (int)p.ldb + schunk * 8) * 2);
         }
     }
-    int vb = blockIdx.x;
-    NtpTile cur = ntp_tile_of(p, vb, full);
-    ntp_stage(p, cur, 0, 0, lds0, wave, oa, ob);
-    if (nk > 1) ntp_stage(p, cur, 1, 1, lds0, wave, oa, ob);
-    bool first = true;
-    for (;;) {
-        const int vn = vb + gridDim.x;
-        const bool more = vn < ntiles;
-        NtpTile nxt = cur;
-        if (more) nxt = ntp_tile_of(p, vn, full);
-        if (cur.half) ntp_run_tile<EPI, true, STAMP>(p, smem, lds0, lane, wave, cur, nxt, more, first, oa, ob, vb);
-        else ntp_run_tile<EPI, false, STAMP>(p, smem, lds0, lane, wave, cur, nxt, more, first, oa, ob, vb);
-        if (!more) break;
-        first = false;
-        cur = nxt;
-        vb = vn;
+    // Tile order.  Static (p.epi.tickets == null): workgroup b walks tiles b, b + G, b + 2G, ...  Dynamic: the workgroups of XCD x draw
+    // tickets k = 0, 1, 2, ... from tickets[x] and compute tile 8 k + x - the tiles the XCD's workgroups walk statically, in the same
+    // order - so a workgroup that starts late or is held up (CUs taken by another stream's kernels or by a collective) computes
+    // fewer tiles instead of holding the launch back by a whole list.  The first ticket is drawn at the start (the one exposed round
+    // trip, ~1 us); from then on the ticket of the next tile is
+    // requested by wave 0 behind the barrier that opens a tile and awaited in front of the tile's last K-tile, a main loop later;
+    // it is handed to the other waves through one LDS word that aliases the first bytes of wave 0's epilogue slab (the kernel owns
+    // all 160 KiB), written and read while no epilogue is running.  (The kernel sits at the SGPR limit: the walk keeps no more
+    // uniform state than the ticket pointer.)
+    unsigned* const tickets = p.epi.tickets ? p.epi.tickets + (blockIdx.x & 7) : nullptr;
+    int vb = blockIdx.x, vn = vb + (int)gridDim.x;
+    if (tickets) {   // the first ticket: the one exposed round trip
+        int* const box = (int*)(smem + 2 * B_STAGE);
+        if (t == 0) *box = (int)atomicAdd(tickets, 1u);
+        __syncthreads();
+        vb = __builtin_amdgcn_readfirstlane(*box) * 8 + (int)(blockIdx.x & 7);
+        __syncthreads();
+    }
+    if (vb < p.tiles_m * p.tiles_n + p.half_tiles) {
+        NtpTile cur = ntp_tile_of(p, vb, p.tiles_m * p.tiles_n);
+        ntp_stage(p, cur, 0, 0, lds0, wave, oa, ob);
+        if (nk > 1) ntp_stage(p, cur, 1, 1, lds0, wave, oa, ob);
+        bool first = true;
+        for (;;) {
+            bool more = false;
+            NtpTile nxt = cur;
+            if (cur.half) ntp_run_tile<EPI, true, STAMP>(smem, lds0, lane, wave, nk, cur, first, oa, ob, vb, tickets, nxt, more, vn);
+            else ntp_run_tile<EPI, false, STAMP>(smem, lds0, lane, wave, nk, cur, first, oa, ob, vb, tickets, nxt, more, vn);
+            if (!more) break;
+            first = false;
+            cur = nxt;
+            vb = vn;
+        }
+    }
+    if (tickets && t == 0) {   // the last workgroup to leave zeroes the tickets for the next launch on this stream (every other
+        unsigned* const tk = tickets - (blockIdx.x & 7);   // workgroup has received its last ticket before it adds to the exit count)
+        if (atomicAdd(tk + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tk[i] = 0u;
+        }
     }
 }
 
@@ -1489,6 +1570,8 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                         cost(tm_b2 * tn_b, ((tm_all - tm_b2) * 2 + tail) * tn_b) + 0.02 < cost(tm_all * tn_b, tail * tn_b))
                         tm_main = tm_b2;
                 }
+                static const bool tickets_on = [] { const char* e = getenv("SC_GEMM_TICKETS"); return !(e && e[0] == '0'); }();   // =0: fixed tile lists (A/B runs)
+                if (!tickets_on || k < 3 * KSTEP) p.epi.tickets = nullptr;   // the ticket protocol needs three K-tiles
                 p.M = (int)m;
                 p.tiles_m = (int)tm_main; p.tiles_n = (int)tn_b;
                 p.half_m0 = (int)(tm_main * B_M);
@@ -1697,6 +1780,40 @@ extern "C" int sc_gemm_bf16_nt(int64_t m, int64_t n, int64_t k, const void* a, i
 // Diagnostic hook, deliberately NOT in include/sparsify_hip.h: tools/gemm_stamps.py sets a device buffer ([tiles][4] uint64) that the
 // stamped instances of the persistent NT kernel fill with s_memtime values; NULL (the default) selects the production instances.
 extern "C" void sc_gemm_bf16_nt_stamps(void* buf) { g_nt_stamps = (unsigned long long*)buf; }
+
+// Diagnostic hook (not in the header): `blocks` workgroups that each keep a CU's registers and LDS for `microseconds` - a stand-in for
+// a collective's kernels when tools/corun_bench.py measures how a GEMM behaves with part of the GPU taken.
+namespace {
+__global__ __launch_bounds__(512) void occupy_kernel(long long ticks, float* sink) {
+    __shared__ float hold[16384];   // 64 KiB: with the persistent GEMM's 160 KiB no GEMM workgroup fits beside this one
+    hold[threadIdx.x] = (float)threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (ticks < 0) sink[0] = hold[(threadIdx.x * 7) & 16383];
+}
+}  // namespace
+// Diagnostic hook (not in the header): leaves every CU's LDS full of NaN bit patterns, so that a test of a kernel that reads LDS it
+// has not written fails every time instead of once in a while (LDS is not cleared between kernels).
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(float* sink) {
+    extern __shared__ unsigned poison[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) poison[i] = 0xffffffffu;
+    __syncthreads();
+    if (sink) sink[0] = __uint_as_float(poison[threadIdx.x]);
+}
+}  // namespace
+extern "C" int sc_debug_poison_lds(void* stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return sc_set_error((int)e, "sc_debug_poison_lds: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 160 * 1024, (hipStream_t)stream, (float*)nullptr);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+extern "C" int sc_debug_occupy(int blocks, int microseconds, void* stream) {
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, (long long)microseconds * 100, (float*)nullptr);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
 
 extern "C" size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t r) {
     if (m <= 0 || n <= 0 || r <= 0) return 0;

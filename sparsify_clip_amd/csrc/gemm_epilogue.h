@@ -18,6 +18,7 @@ struct EpiParams {
     size_t colsum_ws_bytes;
     int colsum_accumulate;
     float* cs_partial;        // device side: [2 * tiles_m][N] partial sums written by the 256x256 NT kernel, or null
+    unsigned* tickets;        // persistent NT kernel: caller-owned tile tickets (16 zeroed words, one stream at a time) or null = static tile lists
     // internal mode 1: w = (m==n) ? 0 : exp(-t * max(rowv[m] + colv[n] - 2*acc, 0))   (pairwise-distance kernel of lunif)
     int mode;
     const float* rowv;
@@ -29,7 +30,7 @@ static inline EpiParams epi_plain(float alpha = 1.f, float beta = 0.f) {
     EpiParams e;
     e.alpha = alpha; e.beta = beta; e.bias = nullptr; e.pre_out = nullptr; e.act = 0; e.resid_dtype = SC_F32;
     e.resid = nullptr; e.dgelu_pre = nullptr; e.ld_aux = 0; e.mode = 0; e.rowv = nullptr; e.colv = nullptr; e.t = 0.f;
-    e.colsum = nullptr; e.colsum_ws = nullptr; e.colsum_ws_bytes = 0; e.colsum_accumulate = 0; e.cs_partial = nullptr;
+    e.colsum = nullptr; e.colsum_ws = nullptr; e.colsum_ws_bytes = 0; e.colsum_accumulate = 0; e.cs_partial = nullptr; e.tickets = nullptr;
     return e;
 }
 
@@ -39,6 +40,8 @@ static inline int epi_from_abi(const sc_gemm_epilogue* a, int /*aux_dtype*/, Epi
     e.alpha = a->alpha; e.beta = a->beta; e.bias = a->bias; e.pre_out = a->pre_out; e.act = a->act;
     e.resid_dtype = a->resid_dtype; e.resid = a->resid; e.dgelu_pre = a->dgelu_pre; e.ld_aux = a->ld_aux;
     e.colsum = a->colsum; e.colsum_ws = a->colsum_ws; e.colsum_ws_bytes = (size_t)a->colsum_ws_bytes; e.colsum_accumulate = a->colsum_accumulate;
+    e.tickets = (unsigned*)a->tile_tickets;
+    if (e.tickets && ((size_t)e.tickets & 63)) return sc_set_error(SC_ERR_ALIGN, "epilogue: tile_tickets must be 64-byte aligned");
     if (e.colsum && !e.colsum_ws) return sc_set_error(SC_ERR_WORKSPACE, "epilogue: colsum needs colsum_ws");
     if (e.act != 0 && e.act != 1) return sc_set_error(SC_ERR_ARG, "epilogue: unknown activation %d", e.act);
     if (e.resid && e.resid_dtype != SC_F32 && e.resid_dtype != SC_BF16) return sc_set_error(SC_ERR_DTYPE, "epilogue: bad resid dtype");

@@ -31,16 +31,17 @@ struct PairParams {
     const bf16_t *xh, *xl;      // [B][E] rows i
     const bf16_t *yh, *yl;      // [B][E] rows j
     const bf16_t *zth, *ztl;    // [E][B] transposed hi / lo of the matrix the second product multiplies (gradient modes)
-    int B, E, nsplit, jt_per_split;
+    int Bi, Bj, E, nsplit, jt_per_split;   // rows of X (i), rows of Y (j); the square case has Bi == Bj
+    int diag_off;               // global index of row i = 0: the pair (i, j) is "on the diagonal" when i + diag_off == j (row-block form)
     float inv_temp, t;
     float coef_row, coef_col, coef_diag;   // CON_GRAD: G = coef_row exp(v - r_i) + coef_col exp(v - c_j) - coef_diag [i == j]
     const float* rowv;          // CON_GRAD: row LSE r_i (rows i);  UNIF: |x_i|^2
     const float* colv;          // CON_GRAD: column LSE c_j (rows j); UNIF: |y_j|^2
-    float* opart;               // [nsplit][B][E] partial second products
-    float *rp_m, *rp_s;         // CON_STATS: [jtiles][B] partial row (max, sum exp)
-    float *cp_m, *cp_s;         // CON_STATS: [itiles][B] partial column (max, sum exp)
-    float* diag;                // CON_STATS: [B] logits on the diagonal
-    float* spart;               // UNIF: [nsplit][B] partial row sums of W
+    float* opart;               // [nsplit][Bi][E] partial second products
+    float *rp_m, *rp_s;         // CON_STATS: [jtiles][Bi] partial row (max, sum exp)
+    float *cp_m, *cp_s;         // CON_STATS: [itiles][Bj] partial column (max, sum exp)
+    float* diag;                // CON_STATS: [Bi] logits on the diagonal
+    float* spart;               // UNIF: [nsplit][Bi] partial row sums of W
     float* scal_part;           // CON_GRAD: sum G v ; SPARS: sum D^2 - one float per workgroup [itiles * nsplit]
 };
 
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
     const int c16 = lane & 15, g = lane >> 4;
     const int it = blockIdx.x, split = blockIdx.y;
     const int i0 = it * PT;
-    const int E = p.E, B = p.B;
-    const int jt0 = split * p.jt_per_split, jt1 = min(B / PT, jt0 + p.jt_per_split);
+    const int E = p.E, Bi = p.Bi, Bj = p.Bj;
+    const int jt0 = split * p.jt_per_split, jt1 = min(Bj / PT, jt0 + p.jt_per_split);
     // staging: thread -> (row t >> 3, 16-byte chunk t & 7) of every [64][64] slice
     const int srow = t >> 3, schunk = (t & 7) * 8;
     const int64_t xoff = (int64_t)(i0 + srow) * E + schunk;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
         if (GRAD) {
 #pragma unroll
             for (int n = 0; n < NT2; ++n) {
-                const int64_t zo = (int64_t)(wave * EC + 16 * n + c16) * B + j0 + 8 * g;
+                const int64_t zo = (int64_t)(wave * EC + 16 * n + c16) * Bj + j0 + 8 * g;
                 zh0[n] = *(const bf16x8*)(p.zth + zo);
                 zl0[n] = *(const bf16x8*)(p.ztl + zo);
                 zh1[n] = *(const bf16x8*)(p.zth + zo + 32);
@@ -212,25 +213,25 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
                         xcol[wr][jl][0] = cm[c][r]; xcol[wr][jl][1] = cs[c][r];
                     }
             }
-            if (it == jt) {   // diagonal logits: i == j  <=>  16 wr + c16 == 16 (2 wc + c) + 4 g + r
+            if (p.diag) {   // diagonal logits: i + diag_off == j
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (16 * wr + c16 == 16 * (2 * wc + c) + 4 * g + r) p.diag[i_lane] = sc[c][r];
+                        if (i_lane + p.diag_off == j0 + 16 * (2 * wc + c) + 4 * g + r) p.diag[i_lane] = sc[c][r];
             }
             __syncthreads();
             if (t < PT) {            // rows: merge the two column halves in a fixed order
                 float m0 = xrow[0][t][0], s0 = xrow[0][t][1];
                 lse_merge(m0, s0, xrow[1][t][0], xrow[1][t][1]);
-                p.rp_m[(int64_t)jt * B + i0 + t] = m0; p.rp_s[(int64_t)jt * B + i0 + t] = s0;
+                p.rp_m[(int64_t)jt * Bi + i0 + t] = m0; p.rp_s[(int64_t)jt * Bi + i0 + t] = s0;
             } else if (t < 2 * PT) { // columns: merge the four row tiles
                 const int jl = t - PT;
                 float m0 = xcol[0][jl][0], s0 = xcol[0][jl][1];
                 lse_merge(m0, s0, xcol[1][jl][0], xcol[1][jl][1]);
                 lse_merge(m0, s0, xcol[2][jl][0], xcol[2][jl][1]);
                 lse_merge(m0, s0, xcol[3][jl][0], xcol[3][jl][1]);
-                p.cp_m[(int64_t)it * B + j0 + jl] = m0; p.cp_s[(int64_t)it * B + j0 + jl] = s0;
+                p.cp_m[(int64_t)it * Bj + j0 + jl] = m0; p.cp_s[(int64_t)it * Bj + j0 + jl] = s0;
             }
             continue;
         }
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
             if (MODE == PM_CON_GRAD || MODE == PM_UNIF) colc = *(const f32x4*)(p.colv + j0 + 16 * (2 * wc + c) + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool dg = (it == jt) && (16 * wr + c16 == 16 * (2 * wc + c) + 4 * g + r);
+                const bool dg = i_lane + p.diag_off == j0 + 16 * (2 * wc + c) + 4 * g + r;
                 const float s = sc[c][r];
                 float v;
                 if (MODE == PM_CON_GRAD) {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
     }
     if (!GRAD) return;
     // ---- outputs of the sweep: O partial, row-sum partial, scalar partial
-    float* od = p.opart + ((int64_t)split * B + i0) * E + wave * EC;
+    float* od = p.opart + ((int64_t)split * Bi + i0) * E + wave * EC;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
         __syncthreads();
         if (g == 0) xrow[wc][16 * wr + c16][0] = rsum;
         __syncthreads();
-        if (t < PT) p.spart[(int64_t)split * B + i0 + t] = xrow[0][t][0] + xrow[1][t][0];
+        if (t < PT) p.spart[(int64_t)split * Bi + i0 + t] = xrow[0][t][0] + xrow[1][t][0];
     } else {
         scal = wave_sum(scal);
         __syncthreads();
@@ -388,7 +389,7 @@ bool sc_pair_supported(int64_t b, int64_t e) { return b >= 2 * PT && b % PT == 0
 
 template <int MODE>
 static int pair_launch(const PairParams& p, hipStream_t st) {
-    const dim3 grid((unsigned)(p.B / PT), (unsigned)p.nsplit);
+    const dim3 grid((unsigned)(p.Bi / PT), (unsigned)p.nsplit);
     switch (p.E / 128) {
 #define CASE(N) case N: hipLaunchKernelGGL((pair_kernel<MODE, N>), grid, dim3(512), 0, st, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -413,7 +414,7 @@ int sc_pair_contrastive(const float* img, const float* txt, int64_t b, int64_t e
     split_launch(img, b, e, w.xh, w.xl, grad ? w.xth : nullptr, grad ? w.xtl : nullptr, st);
     split_launch(txt, b, e, w.yh, w.yl, grad ? w.yth : nullptr, grad ? w.ytl : nullptr, st);
     PairParams p = {};
-    p.xh = w.xh; p.xl = w.xl; p.yh = w.yh; p.yl = w.yl; p.B = (int)b; p.E = (int)e; p.inv_temp = inv_temp;
+    p.xh = w.xh; p.xl = w.xl; p.yh = w.yh; p.yl = w.yl; p.Bi = p.Bj = (int)b; p.E = (int)e; p.inv_temp = inv_temp;
     p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
     p.rp_m = w.rp_m; p.rp_s = w.rp_s; p.cp_m = w.cp_m; p.cp_s = w.cp_s; p.diag = diag;
     SC_TRY(pair_launch<PM_CON_STATS>(p, st));
@@ -449,7 +450,7 @@ int sc_pair_lunif(const float* x, const float* sumsq, int64_t b, int64_t e, floa
     pair_carve(ws, b, e, w);
     split_launch(x, b, e, w.xh, w.xl, w.xth, w.xtl, st);
     PairParams p = {};
-    p.xh = w.xh; p.xl = w.xl; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.B = (int)b; p.E = (int)e; p.t = t;
+    p.xh = w.xh; p.xl = w.xl; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.Bi = p.Bj = (int)b; p.E = (int)e; p.t = t;
     p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
     p.rowv = sumsq; p.colv = sumsq; p.opart = w.opart; p.spart = w.spart; p.scal_part = w.scal_part;
     SC_TRY(pair_launch<PM_UNIF>(p, st));
@@ -465,7 +466,7 @@ int sc_pair_sparsify(const float* x, int64_t b, int64_t e, float grad_scale, flo
     pair_carve(ws, b, e, w);
     split_launch(x, b, e, w.xh, w.xl, w.xth, w.xtl, st);
     PairParams p = {};
-    p.xh = w.xh; p.xl = w.xl; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.B = (int)b; p.E = (int)e;
+    p.xh = w.xh; p.xl = w.xl; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.Bi = p.Bj = (int)b; p.E = (int)e;
     p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
     p.opart = w.opart; p.scal_part = w.scal_part;
     SC_TRY(pair_launch<PM_SPARS>(p, st));

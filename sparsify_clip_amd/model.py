@@ -67,6 +67,7 @@ class _Tower:
         self.descs = []
         self.bufs = {}
         self.events = None
+        self.tickets = None    # tile tickets of the tower's NT GEMMs (one stream at a time: the tower's main stream)
 
 
 class ClipModel:
@@ -331,10 +332,12 @@ class ClipModel:
         tower.descs = []
         if self.dtype == torch.bfloat16 and tower.events is None:
             tower.events = EventSet()    # the blocks of one tower are enqueued one after the other from this thread: one set per tower
+            tower.tickets = torch.zeros(16, dtype=torch.int32, device=dev)   # sc_block_desc.tile_tickets: zeroed once, the kernels leave it zero
         for i in range(tower.layers):
             d = BlockDesc()
             if tower.events is not None:
                 tower.events.bind(d)
+                d.tile_tickets = tower.tickets.data_ptr()
             d.batch, d.seq, d.width, d.heads, d.mlp_width = batch, tower.seq, w, tower.heads, mlp
             d.dtype, d.causal = sc_dtype(T), tower.causal
             p = f"{tower.prefix}{i}."

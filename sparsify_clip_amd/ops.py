@@ -25,8 +25,9 @@ def _workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 
 
 def make_epilogue(alpha=1.0, beta=0.0, bias=None, pre_out=None, act=0, resid=None, dgelu_pre=None, ld_aux=0, colsum=None,
-                  colsum_accumulate=False, rows=None):
-    """colsum ([N] fp32): also receive the column sums of the stored output; `rows` (the GEMM's M) sizes the partial-sum workspace."""
+                  colsum_accumulate=False, rows=None, tile_tickets=None):
+    """colsum ([N] fp32): also receive the column sums of the stored output; `rows` (the GEMM's M) sizes the partial-sum workspace.
+    tile_tickets (>= 16 zeroed int32, one stream at a time): dynamic tile order of the persistent NT kernel."""
     e = GemmEpilogue()
     e.alpha, e.beta, e.act = float(alpha), float(beta), int(act)
     e.bias = bias.data_ptr() if bias is not None else None
@@ -42,7 +43,8 @@ def make_epilogue(alpha=1.0, beta=0.0, bias=None, pre_out=None, act=0, resid=Non
         n = colsum.numel()
         ws = torch.empty(max(4096 * n, ((rows + 127) // 128) * n) * 4, dtype=torch.uint8, device=colsum.device)
         e.colsum, e.colsum_ws, e.colsum_ws_bytes, e.colsum_accumulate = colsum.data_ptr(), ws.data_ptr(), ws.numel(), int(bool(colsum_accumulate))
-    e._keepalive = (bias, pre_out, resid, dgelu_pre, colsum, ws)   # the struct only holds raw pointers
+    e.tile_tickets = tile_tickets.data_ptr() if tile_tickets is not None else None
+    e._keepalive = (bias, pre_out, resid, dgelu_pre, colsum, ws, tile_tickets)   # the struct only holds raw pointers
     return e
 
 

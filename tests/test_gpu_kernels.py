@@ -126,6 +126,54 @@ def test_gemm_bf16_nt_wide(ops, m, n, k):
     assert_close(got, v, 1e-2, 1e-2, "wide bias")
 
 
+@pytest.mark.parametrize("m,n,k", [(65536, 512, 192), (43520, 768, 256), (8192, 2048, 256), (12416, 768, 192)])
+def test_gemm_bf16_nt_tile_tickets(ops, m, n, k):
+    """Dynamic tile order of the persistent NT kernel (sc_gemm_epilogue.tile_tickets): whichever workgroup computes a tile, the stored
+    values are the ones of the fixed tile lists - bit for bit, for the step's four epilogues, with whole and half tiles - the
+    tickets are zero again after every launch, and a launch that shares the GPU with another stream's kernel (a diagnostic kernel
+    keeping 48 CUs) still computes every tile exactly once."""
+    import ctypes
+    from sparsify_clip_amd._lib import LIB
+    a, w = rnd(m, k, seed=31, dtype=torch.bfloat16).to(DEV), rnd(n, k, seed=32, scale=0.1, dtype=torch.bfloat16).to(DEV)
+    bias, resid = rnd(n, seed=33).to(DEV), rnd(m, n, seed=34).to(DEV)
+    pre = rnd(m, n, seed=35, dtype=torch.bfloat16).to(DEV)
+    tk = torch.zeros(16, dtype=torch.int32, device=DEV)
+    occupy = LIB.load().sc_debug_occupy
+    occupy.argtypes, occupy.restype = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int
+    side = torch.cuda.Stream()
+
+    def run(kind, tickets, taken=0):
+        cs = torch.zeros(n, device=DEV)
+        pre_out = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+        kw = dict(tile_tickets=tickets)
+        if kind == "bias":
+            e, od = ops.make_epilogue(bias=bias, ld_aux=n, **kw), torch.bfloat16
+        elif kind == "gelu":
+            e, od = ops.make_epilogue(bias=bias, pre_out=pre_out, act=1, ld_aux=n, **kw), torch.bfloat16
+        elif kind == "resid":
+            e, od = ops.make_epilogue(bias=bias, resid=resid, ld_aux=n, **kw), torch.float32
+        else:
+            e, od = ops.make_epilogue(dgelu_pre=pre, ld_aux=n, colsum=cs, rows=m, **kw), torch.bfloat16
+        if taken:
+            with torch.cuda.stream(side):
+                assert occupy(taken, 1500, ctypes.c_void_p(side.cuda_stream)) == 0
+            torch.cuda._sleep(100000)
+        out = ops.gemm_bf16_nt(a, w, out_dtype=od, epi=e)
+        torch.cuda.synchronize()
+        return out, pre_out, cs
+
+    for kind in ("bias", "gelu", "resid", "dgelu"):
+        ref = run(kind, None)
+        for taken in (0, 48):
+            got = run(kind, tk, taken)
+            assert torch.equal(got[0], ref[0]), f"{kind}: output differs with tile tickets ({taken} CUs taken)"
+            if kind == "gelu":
+                assert torch.equal(got[1], ref[1]), "gelu: pre-activation differs with tile tickets"
+            if kind == "dgelu":
+                assert torch.equal(got[2], ref[2]), "dgelu: fused column sums differ with tile tickets"
+            assert int(tk.abs().sum()) == 0, f"{kind}: tickets not left zero"
+
+
 def test_gemm_bf16_epilogue_gelu_series_accuracy(ops):
     """The bf16 epilogues evaluate GELU / GELU' as odd polynomial series (csrc/common.h); through an fp32-output GEMM with
     acc == x (B = I) resp. acc == 1 the series are compared with the erf forms over [-9, 9]: abs error <= 2e-5 / 3e-5."""
@@ -411,8 +459,18 @@ def _ref_attention(qkv, batch, seq, heads, causal):
     return o.transpose(1, 2).reshape(batch * seq, w)
 
 
+def _poison_lds():
+    """Diagnostic hook of the library: fills every CU's LDS with NaN bit patterns (LDS is not cleared between kernels)."""
+    import ctypes
+    from sparsify_clip_amd._lib import LIB
+    f = LIB.load().sc_debug_poison_lds
+    f.argtypes, f.restype = [ctypes.c_void_p], ctypes.c_int
+    assert f(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (128, 1, False), (128, 2, True), (100, 1, True),
+@pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (5, 2, False), (128, 1, False), (128, 2, True), (100, 1, True),
                                               (90, 1, True), (257, 2, False), (200, 1, True)])
 def test_attention(ops, dtype, seq, heads, causal):
     if seq > 128 and dtype == torch.float32:
@@ -421,6 +479,7 @@ def test_attention(ops, dtype, seq, heads, causal):
     qkv = rnd(batch * seq, 3 * w, seed=51).to(dtype)
     q64 = qkv.double().requires_grad_(True)
     ref = _ref_attention(q64, batch, seq, heads, causal)
+    _poison_lds()
     out = ops.attention_fwd(qkv.to(DEV), batch, seq, heads, causal)
     tol = (1e-5, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
     assert_close(out, ref, *tol, "attention fwd")
@@ -433,6 +492,7 @@ def test_attention(ops, dtype, seq, heads, causal):
     else:      # every other case with a forward (round 1 skipped the backward at 77 < S <= 128)
         d_out = rnd(batch * seq, w, seed=52).to(dtype)
         ref.backward(d_out.double())
+        _poison_lds()   # LDS the kernels do not write themselves reads as NaN (sequence lengths that leave whole tiles of the kernel's shape empty)
         d_qkv = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal)
         tolb = (1e-4, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
         assert_close(d_qkv, q64.grad, *tolb, "attention bwd")

@@ -13,6 +13,9 @@
 #   pmc_loss     FETCH_SIZE / WRITE_SIZE + kernel times of the loss head at B = 8192 -> gpurun_out/pmc/loss_counters.txt
 #   loss         tools/loss_bench.py                       -> gpurun_out/loss_head_times.txt
 #   attn / pmc_attn   tools/attn_bench.py timings / SQ counters of the attention kernels -> gpurun_out/attention_times.txt, pmc/attn_counters.txt
+#   corun        tools/corun_bench.py: the persistent NT GEMM with 16 / 32 / 64 CUs taken by another stream, fixed lists vs tile tickets
+#                                                         -> gpurun_out/gemm_corun.txt
+#   ln           tools/ln_bench.py stand-alone LayerNorm forward / backward rates -> gpurun_out/layernorm_times.txt
 #   dp2          python bench.py --gpus 2 under SC_DIST_BACKEND=gloo on the one GPU (self-launch rehearsal) -> gpurun_out/dp2.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof $R/gpurun_out/pmc $R/gpurun_out/replay
@@ -70,6 +73,10 @@ for task in "$@"; do
       PMC a_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $R/tools/attn_bench.py || exit 1
       PMC a_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES -- $R/tools/attn_bench.py || exit 1
       python3 tools/pmc_table.py attn $R/gpurun_out/pmc/a_sq1 $R/gpurun_out/pmc/a_sq2 > $R/gpurun_out/pmc/attn_counters.txt; cat $R/gpurun_out/pmc/attn_counters.txt ;;
+    corun)
+      timeout -k 10 300 python tools/corun_bench.py > gpurun_out/gemm_corun.txt 2>&1; rc=$?; cat gpurun_out/gemm_corun.txt; [ $rc = 0 ] || exit $rc ;;
+    ln)
+      timeout -k 10 300 python tools/ln_bench.py > gpurun_out/layernorm_times.txt 2>&1; rc=$?; cat gpurun_out/layernorm_times.txt; [ $rc = 0 ] || exit $rc ;;
     attn)
       timeout -k 10 300 python tools/attn_bench.py > gpurun_out/attention_times.txt 2>&1; rc=$?; cat gpurun_out/attention_times.txt; [ $rc = 0 ] || exit $rc ;;
     *) echo "unknown task $task"; exit 2 ;;

@@ -247,7 +247,140 @@ void run_loop(const char* name, const bf16_t* A, const bf16_t* B, bf16_t* C, int
     fflush(stdout);
 }
 
+// 256x256 tile, 8 waves, the whole 160 KiB of LDS as a ring of five 32-KiB half-stages (the A rows or the B rows of one K-tile):
+// A(t) -> slot 2t % 5, B(t) -> slot (2t+1) % 5.  At the mid-tile barrier of tile t the slots of A(t), B(t) are free and take
+// B(t+2), A(t+3); A(t+2) (requested one barrier earlier) is still in flight, so 96 KiB are requested ahead instead of 64.
+template <int NRD, int NMF, bool STORE>
+__global__ __launch_bounds__(512) void ring_kernel(const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, int tiles_m, int tiles_n, float* sink) {
+    constexpr int TM = 256, TN = 256, SLOT = 256 * 128, W = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int GM = 8, GN = 4;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int band = tile / (GM * tiles_n), r_band = tile - band * (GM * tiles_n);
+    const int rows = min(GM, tiles_m - band * GM);
+    const int cell = r_band / (rows * GN), r_cell = r_band - cell * (rows * GN);
+    const int gw = min(GN, tiles_n - cell * GN);
+    const int m0 = (band * GM + r_cell / gw) * TM, n0 = (cell * GN + r_cell % gw) * TN;
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const char *ga[4], *gb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + srow;
+        ga[q] = (const char*)(A + (size_t)min(m0 + r, M - 1) * K) + schunk * 16;
+        gb[q] = (const char*)(B + (size_t)min(n0 + r, N - 1) * K) + schunk * 16;
+    }
+    const int nk = K / 64;
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 fr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fr[i] = s16x8{1, 2, 3, 4, 5, 6, 7, 8};
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned rbase = lds0 + ((wave * 8 + (lane & 15)) * 128) + (((lane >> 4) ^ (lane & 7)) * 16);
+    auto stage = [&](const char* const (&g)[4], int slot, int kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(g[q] + (size_t)kt * 128), (lptr_t)(smem + slot * SLOT + (wave * 4 + q) * 1024), 16, 0, 0);
+    };
+    stage(ga, 0, 0); stage(gb, 1, 0);
+    if (nk > 1) { stage(ga, 2, 1); stage(gb, 3, 1); }
+    if (nk > 2) stage(ga, 4, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int sa = 0;   // slot of A(kt)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int sb = sa + 1 >= 5 ? sa - 4 : sa + 1, sa1 = sa + 2 >= 5 ? sa - 3 : sa + 2, sb1 = sa + 3 >= 5 ? sa - 2 : sa + 3;
+        const unsigned ra = rbase + sa * SLOT, rb = rbase + sb * SLOT, ra1 = rbase + sa1 * SLOT, rb1 = rbase + sb1 * SLOT;
+#pragma unroll
+        for (int i = 0; i < NMF / 2; ++i) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i % 16]) : "v"(fr[i % 4]), "v"(fr[4 + i % 4]));
+            if (NRD > 0 && i % 4 == 0) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(i / 4) % 8]) : "v"(ra), "n"((i / 4) * 2048 + 64) : "memory");
+                if (i / 4 < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(i / 4 + 4) % 8]) : "v"(rb), "n"((i / 4) * 2048 + 64) : "memory");
+            }
+        }
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(gb, sa, kt + 2);
+        if (kt + 3 < nk) stage(ga, sb, kt + 3);
+#pragma unroll
+        for (int i = 0; i < NMF / 2; ++i) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i % 16]) : "v"(fr[i % 4]), "v"(fr[4 + i % 4]));
+            if (NRD > 0 && i % 4 == 0) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(i / 4) % 8]) : "v"(ra1), "n"((i / 4) * 2048) : "memory");
+                if (i / 4 < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(i / 4 + 4) % 8]) : "v"(rb1), "n"((i / 4) * 2048) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        sa = sa1;
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += acc[i][0] + acc[i][3];
+    if (STORE) {
+        constexpr int PER_LANE = TM * TN * 2 / 16 / (W * 64);
+        char* cp = (char*)C + ((size_t)(m0) * N + n0) * 2;
+#pragma unroll 4
+        for (int i = 0; i < PER_LANE; ++i) {
+            const int idx = i * W * 64 + t;
+            const int r = idx / (TN / 8), c = idx % (TN / 8);
+            if (m0 + r < M && n0 + c * 8 < N) *(float4*)(cp + ((size_t)r * N + c * 8) * 2) = float4{tot, tot, tot, tot};
+        }
+    } else if (tot == 123.456f) sink[0] = tot;
+}
+
+template <int NRD, int NMF, bool STORE>
+void run_ring(const char* name, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, float* sink) {
+    const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+    const size_t lds = 5 * 256 * 128;
+    auto kern = ring_kernel<NRD, NMF, STORE>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(512), lds, 0, A, B, C, M, N, K, tm, tn, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    hipError_t err = hipGetLastError();
+    printf("ring %-50s M=%d N=%d K=%d  %8.1f us  flop-equiv %6.0f TF %s\n", name, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12,
+           err ? hipGetErrorString(err) : "");
+    fflush(stdout);
+}
+
 int main() {
+    if (getenv("RING_ONLY")) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const int M = 51200, N = pass ? 768 : 3072, K = pass ? 3072 : 768;
+            bf16_t *A, *B, *C; float* sk;
+            hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2); hipMalloc(&sk, 64);
+            std::vector<bf16_t> h((size_t)M * K);
+            unsigned x = 12345u;
+            for (auto& v : h) { x = x * 1664525u + 1013904223u; const float f = ((x >> 8) & 0xffff) / 32768.f - 1.f + ((x >> 4) & 0xff) / 512.f; unsigned u; memcpy(&u, &f, 4); v = (bf16_t)(u >> 16); }
+            hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
+            hipMemcpy(B, h.data() + 777, (size_t)N * K * 2, hipMemcpyHostToDevice);
+            run_loop<256, 256, 2, 8, 0, 0, false>("256x256 S2 W8 loads only", A, B, C, M, N, K, sk);
+            run_ring<0, 0, false>("256x256 ring5 W8 loads only", A, B, C, M, N, K, sk);
+            run_loop<256, 256, 2, 8, 0, 64, false>("256x256 S2 W8 loads+64mfma", A, B, C, M, N, K, sk);
+            run_ring<0, 64, false>("256x256 ring5 W8 loads+64mfma", A, B, C, M, N, K, sk);
+            run_loop<256, 256, 2, 8, 24, 64, false>("256x256 S2 W8 full loop", A, B, C, M, N, K, sk);
+            run_ring<24, 64, false>("256x256 ring5 W8 full loop", A, B, C, M, N, K, sk);
+            run_loop<256, 256, 2, 8, 24, 64, true>("256x256 S2 W8 full loop + C stores", A, B, C, M, N, K, sk);
+            run_ring<24, 64, true>("256x256 ring5 W8 full loop + C stores", A, B, C, M, N, K, sk);
+            hipFree(A); hipFree(B); hipFree(C); hipFree(sk);
+        }
+        return 0;
+    }
     if (getenv("LOOP_ONLY")) {
         const int M = 51200, N = 3072, K = 768;
         bf16_t *A, *B, *C; float* sk;
