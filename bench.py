@@ -140,13 +140,15 @@ def gemm_roofline(model, device):
         del a, b, out, keep, epi
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic*.json")))   # the latest committed PMC pass (tools/gpu.sh pmc_traffic)
+    tpath = tfiles[-1] if tfiles else ""
+    if tpath:
         with open(tpath) as f:
             t = json.load(f)
         if t.get("launches") == count and t.get("local_batch") == model.visual.batch:
             traffic = t["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt (256x256 AGPR kernel + 256x128 kernel; every NT launch of one step with its fused epilogue)",
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_pers_kernel (persistent 256x256 AGPR kernel; every NT launch of one step with its fused epilogue)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": count,
             "avg_launch_us": round(total_ms * 1e3 / count, 1), "flops_per_launch_avg": total_flops / count,
