@@ -6,7 +6,7 @@ reference instantiates at sparsify_clip.py:685-689 and calls at :768-769 (ViT-B-
 pre-LN residual attention blocks, nn.MultiheadAttention with packed in_proj, exact-erf GELU, LayerNorm
 eps 1e-5, cls-token pooling after ln_post, argmax(EOT) text pooling, bias-free projections, causal text
 mask).  Parameter names follow open_clip's state_dict so that a real checkpoint could settle parity later.
-Cross-checks that do hold: 151.28 M / 427.62 M parameters (tests/test_model_cpu.py).
+Cross-checks that do hold: 151.28 M / 427.62 M parameters (tests/test_host_logic.py).
 """
 from __future__ import annotations
 
