@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--cpu-batch", type=int, default=32)
     p.add_argument("--input-pipeline", type=int, default=0, help="N = 1 only: after the timed region, time the step again with every batch "
                    "coming through the host assembly + H2D copy + device augmentation of sparsify_clip_amd/input_pipeline.py (uint8 COCO-sized images)")
+    p.add_argument("--text-trim", type=int, default=1, help="N = 1 only: after the timed region, time the step again with `text_trim: True` (the "
+                   "text tower runs over the batch's longest caption instead of all 77 positions; same results) and report it as 'with_text_trim'; "
+                   "the headline value always computes every position, as the reference does")
     p.add_argument("--simulate-dp", type=int, default=8, help="N = 1 only: after the timed region, time the step again with the loss head fed a "
                    "global batch of simulate_dp x local_batch rows (filler rows for the absent ranks) = the per-GPU work of that DP job; 1 = off")
     return p.parse_args()
@@ -267,6 +270,25 @@ def main():
         out["dp_rank_equivalent"] = {"simulated_world": args.simulate_dp, "loss_head_batch": args.simulate_dp * args.local_batch,
                                      "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
                                      "note": "compute of one rank of the DP job (global-batch loss head replicated), collectives excluded"}
+    if world == 1 and args.text_trim:
+        # opt-in: text tower over the longest caption of the batch only (padding behind EOT cannot influence the result under the causal mask)
+        from sparsify_clip_amd.data import caption_length
+        lens = [caption_length(b[1]) for b in batches]
+        trainer.config["text_trim"] = True
+        for i in range(2):
+            trainer.step(*batches[i % 2], text_len=lens[i % 2])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ntrim = min(args.steps, 8)
+        for i in range(ntrim):
+            trainer.step(*batches[i % 2], text_len=lens[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / ntrim
+        trainer.config["text_trim"] = False
+        out["with_text_trim"] = {"ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(args.local_batch / dt, 1), "longest_caption_tokens": max(lens),
+                                 "note": "config key text_trim: the text tower runs over the batch's longest caption (synthetic captions: 5-30 words + SOT/EOT, "
+                                         "SURVEY 8d) rounded up to a multiple of 8 instead of all 77 positions; embeddings and gradients are the same "
+                                         "(tests/test_gpu_model.py::test_text_trim_equivalence); not the headline value"}
     if world == 1 and args.input_pipeline:
         # the same step fed by the real input path: uint8 pixels -> pinned staging -> H2D on a side stream -> device crop/resize/flip/normalise
         from sparsify_clip_amd.input_pipeline import DeviceAugLoader, SyntheticCocoDataset

@@ -38,6 +38,11 @@ class HashTokenizer:
         return out
 
 
+def caption_length(tokens) -> int:
+    """Longest caption of a tokenised batch, EOT included (EOT is the largest id: open_clip pools at argmax, reference :769)."""
+    return int(tokens.argmax(dim=1).max()) + 1
+
+
 def get_tokenizer(model_name=None, context_length=CTX, vocab=VOCAB):
     """Mirror of open_clip.get_tokenizer(name) (reference :692, :560)."""
     return HashTokenizer(context_length, vocab)

@@ -68,6 +68,9 @@ class _Tower:
         self.bufs = {}
         self.events = None
         self.tickets = None    # tile tickets of the tower's NT GEMMs (one stream at a time: the tower's main stream)
+        self.run_seq = seq     # sequence length of the current forward / backward (text tower: <= seq when the batch is trimmed)
+        self.run_descs = None  # the block descriptors in use (tower.descs, or their copies with seq = run_seq)
+        self.trimmed = {}      # run_seq -> descriptor copies
 
 
 class ClipModel:
@@ -330,6 +333,8 @@ class ClipModel:
                 self._scratch[f"bwd.{tower.kind}.{key}"] = torch.empty(n, dtype=dt, device=dev)
         tower.batch = batch
         tower.descs = []
+        tower.trimmed = {}
+        tower.run_descs, tower.run_seq = None, tower.seq
         if self.dtype == torch.bfloat16 and tower.events is None:
             tower.events = EventSet()    # the blocks of one tower are enqueued one after the other from this thread: one set per tower
             tower.tickets = torch.zeros(16, dtype=torch.int32, device=dev)   # sc_block_desc.tile_tickets: zeroed once, the kernels leave it zero
@@ -365,6 +370,7 @@ class ClipModel:
 
     def _bind_scratch(self):
         for tower in (self.visual, self.text):
+            tower.trimmed = {}
             for i, d in enumerate(tower.descs):
                 k = (tower.layers - 1 - i) % 2          # position in the backward order selects the scratch set
                 fam = f"bwd.{tower.kind}."
@@ -382,8 +388,25 @@ class ClipModel:
             return ops.gemm_bf16_nt(x, w)
         return ops.gemm_f32(x, w, trans_b=True)
 
+    def _use_seq(self, tower, seq):
+        """Select the descriptors of a forward / backward over `seq` <= tower.seq positions per sample: the same buffers (a
+        [batch * seq, W] prefix of each), copies of the descriptors with the shorter sequence length."""
+        if seq == tower.seq:
+            tower.run_descs, tower.run_seq = tower.descs, seq
+            return
+        if seq not in tower.trimmed:
+            import ctypes
+            copies = []
+            for d in tower.descs:
+                c = BlockDesc()
+                ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(BlockDesc))
+                c.seq = seq
+                copies.append(c)
+            tower.trimmed[seq] = copies
+        tower.run_descs, tower.run_seq = tower.trimmed[seq], seq
+
     def _blocks_fwd(self, tower):
-        for d in tower.descs:
+        for d in (tower.run_descs or tower.descs):
             ops.block_fwd(d)
 
     def _blocks_bwd(self, tower, dx, acc):
@@ -395,7 +418,7 @@ class ClipModel:
         bf = self.dtype == torch.bfloat16
         if not bf:
             for i in reversed(range(tower.layers)):
-                d = tower.descs[i]
+                d = (tower.run_descs or tower.descs)[i]
                 d.accumulate = int(acc)
                 ops.block_bwd(d, dx, None, dx, None)
                 if self.comm is not None:
@@ -420,7 +443,7 @@ class ClipModel:
                 s0, layer0 = pending.pop(0)
                 if self.comm is not None:
                     self.comm.bucket_ready(f"{tower.prefix}{layer0}.")
-            d = tower.descs[i]
+            d = (tower.run_descs or tower.descs)[i]
             d.accumulate = int(acc)
             ops.block_bwd(d, dx, dx_t[step % 3], dx, dx_t[(step + 1) % 3], side_stream=side)
             side_done[step % 2].record(side)
@@ -490,23 +513,36 @@ class ClipModel:
         if self.comm is not None:
             self.comm.bucket_ready("visual.stem")
 
-    def text_forward(self, tokens):
+    def text_forward(self, tokens, seq_len=None):
+        """seq_len (optional, host int): the batch's longest caption in tokens, EOT included.  Under the causal mask nothing at or
+        before a caption's EOT sees the positions behind it, the tower's output is taken AT the EOT and the positions behind it
+        receive an exactly-zero gradient, so running the tower over the first `seq_len` positions only gives the same embeddings and
+        the same parameter gradients (up to fp32 summation order) as running it over all 77 - with 77 / seq_len times fewer rows in
+        every text GEMM.  The caller must know the length on the host (the tokenizer does); None = all positions, as the reference."""
         c, tw = self.cfg, self.text
         if tokens.dim() != 2 or tokens.shape[1] != c["ctx"]:
             raise ScError(f"encode_text expects int64 [B,{c['ctx']}], got {tuple(tokens.shape)}")
         tokens = tokens.to(device=self.device, dtype=torch.int64).contiguous()
         batch = tokens.shape[0]
         self._prepare(tw, batch)
+        seq = tw.seq
+        if seq_len is not None:
+            if not 1 <= int(seq_len) <= tw.seq:
+                raise ScError(f"encode_text: seq_len {seq_len} outside 1..{tw.seq}")
+            seq = min(tw.seq, (int(seq_len) + 7) // 8 * 8)      # a few distinct lengths only (descriptor copies are cached per length)
+            if seq < tw.seq:
+                tokens = tokens[:, :seq].contiguous()
+        self._use_seq(tw, seq)
         b = tw.bufs
         b["tokens"] = tokens
         ops.text_embed_fwd(tokens, self.param("token_embedding.weight"), self.param("positional_embedding"), out=b["x"][0])
         self._blocks_fwd(tw)
         b["eot"] = ops.argmax_tokens(tokens)
         if self.training:   # bookkeeping of the backward pass, done here so that it runs under the forward GEMMs instead of at the tail of the step
-            b["sorted_keys"], b["sort_order"] = self._token_sort(tokens, b["eot"], tw.seq)
+            b["sorted_keys"], b["sort_order"] = self._token_sort(tokens, b["eot"], seq)
         else:
             b.pop("sorted_keys", None)
-        b["pooled"] = ops.pool_gather(b["x"][-1], b["eot"], batch, tw.seq)
+        b["pooled"] = ops.pool_gather(b["x"][-1], b["eot"], batch, seq)
         b["pooled_ln"], b["post_mean"], b["post_rstd"] = ops.layernorm_fwd(b["pooled"], self.param("ln_final.weight"), self.param("ln_final.bias"),
                                                                            torch.float32)
         return ops.gemm_f32(b["pooled_ln"], self.param("text_projection"))
@@ -531,16 +567,20 @@ class ClipModel:
                                               dgamma=self.grad("ln_final.weight"), dbeta=self.grad("ln_final.bias"), accumulate=acc)
         if self.comm is not None:
             self.comm.bucket_ready("text.head")
-        dx = self._scratch["bwd.text.dx"][: batch * tw.seq * tw.width].view(batch * tw.seq, tw.width)
+        seq = tw.run_seq
+        dx = self._scratch["bwd.text.dx"][: batch * seq * tw.width].view(batch * seq, tw.width)
         dx.zero_()
-        ops.pool_scatter(d_pooled, b["eot"], batch, tw.seq, dx)
+        ops.pool_scatter(d_pooled, b["eot"], batch, seq, dx)
         self._blocks_bwd(tw, dx, acc)
         # token-embedding scatter-add in a fixed order (the index sort is bookkeeping done in text_forward, the fp32 sums are the
         # HIP kernel's)
         if "sorted_keys" not in b:   # forward ran in eval mode
-            b["sorted_keys"], b["sort_order"] = self._token_sort(b["tokens"], b["eot"], tw.seq)
+            b["sorted_keys"], b["sort_order"] = self._token_sort(b["tokens"], b["eot"], seq)
         st, order = b["sorted_keys"], b["sort_order"]
-        ops.text_embed_bwd(dx, st, order, batch, tw.seq, self.grad("token_embedding.weight"), self.grad("positional_embedding"), acc)
+        d_pos = self.grad("positional_embedding")
+        if seq < tw.seq and not acc:
+            d_pos[seq:].zero_()      # positions the trimmed batch never reaches: gradient exactly zero
+        ops.text_embed_bwd(dx, st, order, batch, seq, self.grad("token_embedding.weight"), d_pos, acc)
         if self.comm is not None:
             self.comm.bucket_ready("text.stem")
 

@@ -22,7 +22,7 @@ from . import dist as D
 from . import ops
 from . import uniformity as U
 from ._lib import ScError
-from .data import SyntheticLoader, get_tokenizer
+from .data import SyntheticLoader, caption_length, get_tokenizer
 from .loss_dispatch import step_loss, validate_loss_type
 from .model import create_model_and_transforms
 from .optim import AdamW
@@ -80,10 +80,18 @@ class Trainer:
         self.pending_logs = []
         self.text_stream = None
 
-    def step(self, images, captions):
+    def step(self, images, captions, text_len=None):
+        """text_len (optional): the batch's longest caption in tokens (EOT included), known on the host.  With `text_trim: True` in the
+        config (an extra key, default False = every position as the reference) the text tower then runs over that many positions
+        only - same embeddings, same gradients (ClipModel.text_forward); without a given length it is read from the tokens,
+        which costs a host sync when they are already on the device."""
         cfg, m = self.config, self.model
         self.current_batch += 1                                                    # :755
         tokens = captions if isinstance(captions, torch.Tensor) else self.tokenizer(captions)   # :762
+        if not cfg.get("text_trim", False):
+            text_len = None
+        elif text_len is None:
+            text_len = caption_length(tokens)
         # the two towers are independent until the loss head: the text tower runs on its own HIP stream so that its HBM-bound
         # kernels (LayerNorm, attention, embedding) overlap the image tower's GEMMs and vice versa
         main = torch.cuda.current_stream()
@@ -92,7 +100,7 @@ class Trainer:
             self.text_stream = torch.cuda.Stream(device=self.device, priority=-1 if os.environ.get("SC_STREAM_PRIO", "") == "t" else 0)
         self.text_stream.wait_stream(main)
         with torch.cuda.stream(self.text_stream):
-            txt_e = m.text_forward(tokens)                                         # :769
+            txt_e = m.text_forward(tokens, seq_len=text_len)                       # :769
         img_e = m.image_forward(images)                                            # :768
         main.wait_stream(self.text_stream)
         send = D.gather_send_buffer(img_e.shape[0], img_e.shape[1], img_e.device)[0] if D.active() else (None, None)

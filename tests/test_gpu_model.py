@@ -413,3 +413,52 @@ def test_c5_vit_l14_step_runs_bf16(pkg):
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][3], outs[1][3])
     assert all(np.isfinite(l) for l in outs[0][0])
     assert 0.0 < outs[0][1] <= 1.0 and 1.0 <= outs[0][2] <= 2.0
+
+
+@pytest.mark.parametrize("name,precision,batch", [("test-small", "fp32", 8), ("test-small", "bf16", 8), ("ViT-B-32", "bf16", 128)])
+def test_text_trim_equivalence(pkg, name, precision, batch):
+    """`text_trim` (ClipModel.text_forward(seq_len=...)): running the text tower over the batch's longest caption only gives the
+    embeddings and parameter gradients of the full 77-position run - positions behind a caption's EOT influence nothing under the
+    causal mask and receive a zero gradient.  fp32 path: equal to fp32 summation order; bf16 path: the kept rows go through the
+    same kernels with the same operands (bit-equal embeddings are not required, bf16-level agreement is).  Also at the trainer
+    level: two steps with `text_trim: True` give the losses of two steps without."""
+    from sparsify_clip_amd.data import caption_length, synthetic_batch
+    model = pkg.ClipModel(name, device=DEV, precision=precision, seed=5)
+    model.train()
+    c = model.cfg
+    images, tokens = [t.to(DEV) for t in synthetic_batch(77, batch, c["image_size"], c["ctx"], c["vocab"])]
+    length = caption_length(tokens)
+    assert 7 <= length <= 32
+    d_emb = torch.randn(batch, c["embed_dim"], device=DEV)
+    got = {}
+    for tag, seq_len in (("full", None), ("trim", length)):
+        model.zero_grad()
+        emb = model.text_forward(tokens, seq_len=seq_len).clone()
+        model.text_backward(d_emb)
+        torch.cuda.synchronize()
+        grads = {k: model.grad(k).clone() for k in ("token_embedding.weight", "positional_embedding", "text_projection", "ln_final.weight",
+                                                   "transformer.resblocks.0.attn.in_proj_weight", "transformer.resblocks.0.mlp.c_fc.weight",
+                                                   "transformer.resblocks.0.mlp.c_proj.bias", "transformer.resblocks.0.ln_1.weight")}
+        got[tag] = (emb, grads)
+    assert model.text.run_seq == (length + 7) // 8 * 8 < c["ctx"]
+    tol_e, tol_g = (1e-6, 1e-5) if precision == "fp32" else (1e-3, 2e-2)
+    assert rel_err(got["trim"][0], got["full"][0]) < tol_e
+    for k, g in got["full"][1].items():
+        assert rel_err(got["trim"][1][k], g) < tol_g, k
+    assert float(got["trim"][1]["positional_embedding"][model.text.run_seq:].abs().max()) == 0.0
+    assert float(got["full"][1]["positional_embedding"][length:].abs().max()) == 0.0      # the full run agrees: nothing reaches those rows
+    if name == "test-small":
+        from conftest import load_json
+        from sparsify_clip_amd.config import finalize_config
+        from sparsify_clip_amd.train import Trainer
+        cfgs = load_json("configs.json")
+        raw = cfgs[[k for k in cfgs if "experiment_6-" in k][0]]
+        losses = {}
+        for trim in (False, True):
+            cfg = finalize_config(raw, 0, {"model": name, "batch_size": batch, "precision": precision})
+            cfg["text_trim"] = trim
+            tr = Trainer(cfg, DEV, 10, model=pkg.ClipModel(name, device=DEV, precision=precision, seed=5))
+            tr.epoch = 1
+            losses[trim] = [tr.step(images, tokens).item() for _ in range(3)]
+        for a, b in zip(losses[False], losses[True]):
+            assert abs(a - b) <= (2e-5 if precision == "fp32" else 2e-2) * abs(a), (losses,)
