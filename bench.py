@@ -256,7 +256,7 @@ def main():
            "last_loss": last_loss,
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
     if world == 1 and args.simulate_dp > 1:
-        # what ONE rank of a simulate_dp-GPU job computes per step (replicated global-batch loss head included; no collective)
+        # what ONE rank of a simulate_dp-GPU job computes per step (its row block of the global-batch loss head included; no collective)
         D.simulate_world(args.simulate_dp)
         trainer.step(*batches[0])
         torch.cuda.synchronize()
@@ -269,7 +269,8 @@ def main():
         D.simulate_world(1)
         out["dp_rank_equivalent"] = {"simulated_world": args.simulate_dp, "loss_head_batch": args.simulate_dp * args.local_batch,
                                      "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
-                                     "note": "compute of one rank of the DP job (global-batch loss head replicated), collectives excluded"}
+                                     "note": "compute of one rank of the DP job: the loss head takes this rank's 1/world of the rows against the whole gathered batch "
+                                             "(step_loss_rows); the statistics exchange and the other collectives are not simulated"}
     if world == 1 and args.text_trim:
         # opt-in: text tower over the longest caption of the batch only (padding behind EOT cannot influence the result under the causal mask)
         from sparsify_clip_amd.data import caption_length

@@ -126,6 +126,24 @@ int sc_lalign_fwd_bwd(const float* x, const float* y, int64_t b, int64_t e, floa
 /* sparsify_loss(x)  :166-176 */
 int sc_sparsify_fwd_bwd(const float* x, int64_t b, int64_t e, float grad_scale, float* loss_out, float* d_x,
                         void* ws, size_t ws_bytes, void* stream);
+/* Row-block ("sharded") forms of the two O(B^2) terms for data-parallel training: the caller holds the gathered [b,e] embeddings and
+ * owns rows [row0, row0 + bm) of them.  *_stats runs before the ranks exchange their statistics, *_grad after it; every rank
+ * then has the same loss value and its own rows of the gradients - (b / bm) times less work per rank than the replicated call.
+ * Needs b % 64 == 0, e % 128 == 0 (e <= 1024), row0 % 64 == 0, bm % 64 == 0 (SC_ERR_SHAPE otherwise: use the replicated call);
+ * ws as for the replicated calls (sc_loss_workspace_bytes(b, e)); nothing is kept between the two calls.
+ *   contrastive (:110-132): stats[3*bm] = row LSE of my image rows | column LSE of my text columns | diagonal logits of my rows;
+ *     _grad takes the three statistics gathered over all ranks ([b] each, rank-major = row order), writes the loss (identical on
+ *     every rank), my rows of d_img / d_txt and, if d_temp_part != NULL, my rows' part of d loss / d temperature (SUM over ranks).
+ *   lunif (:159-164): _stats gives my rows of the row sums of W and of W X plus s_part = their sum; _grad takes every rank's s_part. */
+int sc_contrastive_rows_stats(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float temperature,
+                              float* stats, void* ws, size_t ws_bytes, void* stream);
+int sc_contrastive_rows_grad(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float temperature,
+                             float grad_scale, const float* row_lse, const float* col_lse, const float* diag, float* loss_out,
+                             float* d_img_rows, float* d_txt_rows, float* d_temp_part, void* ws, size_t ws_bytes, void* stream);
+int sc_lunif_rows_stats(const float* x, int64_t b, int64_t e, int64_t row0, int64_t bm, float t, float* rowsum_rows, float* wx_rows,
+                        float* s_part, void* ws, size_t ws_bytes, void* stream);
+int sc_lunif_rows_grad(const float* x_rows, int64_t b, int64_t bm, int64_t e, float t, float grad_scale, const float* s_parts, int64_t nparts,
+                       const float* rowsum_rows, const float* wx_rows, float* loss_out, float* dx_rows, void* stream);
 /* Row L2 normalisation y = x / max(||x||, eps); eps = 0 reproduces :772-773 (no clamp), eps = 1e-12 F.normalize (:804).
  * inv_norm [B] is saved for the backward. */
 int sc_l2norm_fwd(const float* x, int64_t b, int64_t e, float eps, float* y, float* inv_norm, void* stream);

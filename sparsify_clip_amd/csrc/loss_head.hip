@@ -19,6 +19,13 @@ int sc_pair_contrastive(const float* img, const float* txt, int64_t b, int64_t e
                         float* d_img, float* d_txt, float** dtemp_part, int* n_dtemp, void* ws, hipStream_t st);
 int sc_pair_lunif(const float* x, const float* sumsq, int64_t b, int64_t e, float t, float* rowsum, float* wx, void* ws, hipStream_t st);
 int sc_pair_sparsify(const float* x, int64_t b, int64_t e, float grad_scale, float* loss_out, float* dx, float* scratch_be, void* ws, hipStream_t st);
+bool sc_pair_rows_supported(int64_t b, int64_t e, int64_t row0, int64_t bm);
+int sc_pair_contrastive_rows_stats(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float inv_temp, float* r_rows,
+                                   float* c_rows, float* diag_rows, void* ws, hipStream_t st);
+int sc_pair_contrastive_rows_grad(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float inv_temp, float grad_scale,
+                                  const float* r_all, const float* c_all, float* d_img_rows, float* d_txt_rows, float* gv_out, void* ws, hipStream_t st);
+int sc_pair_lunif_rows(const float* x, const float* sumsq, int64_t b, int64_t e, int64_t row0, int64_t bm, float t, float* rowsum_rows, float* wx_rows,
+                       void* ws, hipStream_t st);
 
 namespace {
 
@@ -551,6 +558,87 @@ extern "C" int sc_axpy_f32(int64_t n, float alpha, const float* x, float* y, voi
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
+// ----------------------------------------------------------------------------- row-block (sharded) loss head
+namespace {
+// S = sum of the ranks' partial sums (fixed order); loss = log(S / (B(B-1))); dX_rows = gs * (-4t/S) * (s_i x_i - (W X)_i) for my rows
+__global__ __launch_bounds__(256) void lunif_rows_grad_kernel(const float* x_rows, const float* wx_rows, const float* rowsum_rows, const float* s_parts,
+                                                              int nparts, int64_t b, int64_t bm, int64_t e, float t, float gs, float* loss_out,
+                                                              float* dx_rows) {
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += s_parts[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) loss_out[0] = logf(s / ((float)b * (float)(b - 1)));
+    if (!dx_rows) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= bm * e) return;
+    const int64_t row = i / e;
+    const float coef = gs * (-4.f * t) / s;
+    dx_rows[i] = coef * (rowsum_rows[row] * x_rows[i] - wx_rows[i]);
+}
+__global__ __launch_bounds__(256) void sum_to_scalar_kernel(const float* v, int64_t n, float scale, float* out) {
+    __shared__ float sm[4];
+    const float s = serial_block_sum(v, n, sm);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+int check_rows(const char* who, int64_t b, int64_t e, int64_t row0, int64_t bm, const void* ws, size_t ws_bytes) {
+    SC_TRY(check_common(who, b, e, ws, ws_bytes));
+    SC_REQUIRE(fused_on() && sc_pair_rows_supported(b, e, row0, bm), SC_ERR_SHAPE,
+               "%s: the row-block loss head needs B %% 64 == 0, E %% 128 == 0 (E <= 1024), row0 and rows multiples of 64 (got B %lld, E %lld, rows %lld + %lld)",
+               who, (long long)b, (long long)e, (long long)row0, (long long)bm);
+    return SC_OK;
+}
+}  // namespace
+
+extern "C" int sc_contrastive_rows_stats(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float temperature,
+                                         float* stats, void* ws, size_t ws_bytes, void* stream_) {
+    SC_TRY(check_rows("sc_contrastive_rows_stats", b, e, row0, bm, ws, ws_bytes));
+    SC_REQUIRE(img && txt && stats && temperature != 0.f, SC_ERR_ARG, "sc_contrastive_rows_stats: bad argument");
+    LossWs w;
+    ws_layout(b, e, ws, &w);
+    return sc_pair_contrastive_rows_stats(img, txt, b, e, row0, bm, 1.0f / temperature, stats, stats + bm, stats + 2 * bm, w.mat, (hipStream_t)stream_);
+}
+
+extern "C" int sc_contrastive_rows_grad(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float temperature,
+                                        float grad_scale, const float* row_lse, const float* col_lse, const float* diag, float* loss_out,
+                                        float* d_img_rows, float* d_txt_rows, float* d_temp_part, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SC_TRY(check_rows("sc_contrastive_rows_grad", b, e, row0, bm, ws, ws_bytes));
+    SC_REQUIRE(img && txt && row_lse && col_lse && diag && loss_out && d_img_rows && d_txt_rows && temperature != 0.f, SC_ERR_ARG,
+               "sc_contrastive_rows_grad: bad argument");
+    LossWs w;
+    ws_layout(b, e, ws, &w);
+    const float inv_t = 1.0f / temperature;
+    hipLaunchKernelGGL(contrastive_loss_kernel, dim3(1), dim3(256), 0, st, row_lse, col_lse, diag, b, loss_out);
+    SC_TRY(sc_pair_contrastive_rows_grad(img, txt, b, e, row0, bm, inv_t, grad_scale, row_lse, col_lse, d_img_rows, d_txt_rows,
+                                         d_temp_part ? w.scal : nullptr, w.mat, st));
+    if (d_temp_part) hipLaunchKernelGGL(dtemp_final_kernel, dim3(1), dim3(256), 0, st, w.scal, 1, inv_t, d_temp_part);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_lunif_rows_stats(const float* x, int64_t b, int64_t e, int64_t row0, int64_t bm, float t, float* rowsum_rows, float* wx_rows,
+                                   float* s_part, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SC_TRY(check_rows("sc_lunif_rows_stats", b, e, row0, bm, ws, ws_bytes));
+    SC_REQUIRE(x && rowsum_rows && wx_rows && s_part, SC_ERR_ARG, "sc_lunif_rows_stats: null argument");
+    LossWs w;
+    ws_layout(b, e, ws, &w);
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(rows4(b)), dim3(256), 0, st, x, b, e, w.colv);
+    SC_TRY(sc_pair_lunif_rows(x, w.colv, b, e, row0, bm, t, rowsum_rows, wx_rows, w.mat, st));
+    hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, rowsum_rows, bm, 1.f, s_part);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+extern "C" int sc_lunif_rows_grad(const float* x_rows, int64_t b, int64_t bm, int64_t e, float t, float grad_scale, const float* s_parts, int64_t nparts,
+                                  const float* rowsum_rows, const float* wx_rows, float* loss_out, float* dx_rows, void* stream_) {
+    SC_REQUIRE(x_rows && s_parts && rowsum_rows && wx_rows && loss_out && b > 1 && bm > 0 && e > 0 && nparts > 0 && nparts <= 4096, SC_ERR_ARG,
+               "sc_lunif_rows_grad: bad argument");
+    hipLaunchKernelGGL(lunif_rows_grad_kernel, dim3((unsigned)sc_cdiv(bm * e, 256)), dim3(256), 0, (hipStream_t)stream_, x_rows, wx_rows, rowsum_rows,
+                       s_parts, (int)nparts, b, bm, e, t, grad_scale, loss_out, dx_rows);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
 extern "C" int sc_retrieval_ranks(const float* score, int64_t n, int32_t* rank_fwd, int32_t* rank_bwd, int32_t* top1_fwd, int32_t* top1_bwd,
                                   void* stream_) {
     SC_REQUIRE(score && rank_fwd && rank_bwd && top1_fwd && top1_bwd && n > 0, SC_ERR_ARG, "sc_retrieval_ranks: bad argument");

@@ -477,3 +477,86 @@ int sc_pair_sparsify(const float* x, int64_t b, int64_t e, float grad_scale, flo
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ row-block forms (sharded loss head)
+// Rank r of a data-parallel job owns rows [row0, row0 + bm) of the gathered batch: the sweeps below visit the bm x B rectangle of its
+// rows against every column instead of the B x B square.  Same kernels (Bi = bm, Bj = B, diagonal at i + row0 == j), same
+// workspace layout as the square forms (the partial buffers of a rectangle never exceed those of the square).
+static int pair_nsplit_rows(int64_t bm, int64_t b) {
+    const int64_t it = bm / PT, jt = b / PT;
+    static const int wgs = [] { const char* e = getenv("SC_PAIR_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    int64_t s = wgs / it;
+    if (s < 1) s = 1;
+    if (s > jt) s = jt;
+    return (int)s;
+}
+bool sc_pair_rows_supported(int64_t b, int64_t e, int64_t row0, int64_t bm) {
+    return sc_pair_supported(b, e) && bm >= PT && bm % PT == 0 && row0 >= 0 && row0 % PT == 0 && row0 + bm <= b;
+}
+
+// row LSE of I_R T^T / temp (r of my rows), row LSE of T_R I^T / temp (= column LSE c of my columns), diagonal logits of my rows
+int sc_pair_contrastive_rows_stats(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float inv_temp, float* r_rows,
+                                   float* c_rows, float* diag_rows, void* ws, hipStream_t st) {
+    PairWs w;
+    pair_carve(ws, b, e, w);
+    split_launch(img, b, e, w.xh, w.xl, nullptr, nullptr, st);
+    split_launch(txt, b, e, w.yh, w.yl, nullptr, nullptr, st);
+    PairParams p = {};
+    p.Bi = (int)bm; p.Bj = (int)b; p.E = (int)e; p.inv_temp = inv_temp; p.diag_off = (int)row0;
+    p.nsplit = pair_nsplit_rows(bm, b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
+    p.rp_m = w.rp_m; p.rp_s = w.rp_s; p.cp_m = w.cp_m; p.cp_s = w.cp_s;
+    const int parts = (int)(b / PT);
+    const unsigned fb = (unsigned)sc_cdiv(bm, 256);
+    p.xh = w.xh + row0 * e; p.xl = w.xl + row0 * e; p.yh = w.yh; p.yl = w.yl; p.diag = diag_rows;          // rows = my images, columns = all texts
+    SC_TRY(pair_launch<PM_CON_STATS>(p, st));
+    hipLaunchKernelGGL(lse_final_kernel, dim3(fb), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)bm, r_rows);
+    p.xh = w.yh + row0 * e; p.xl = w.yl + row0 * e; p.yh = w.xh; p.yl = w.xl; p.diag = nullptr;            // rows = my texts, columns = all images
+    SC_TRY(pair_launch<PM_CON_STATS>(p, st));
+    hipLaunchKernelGGL(lse_final_kernel, dim3(fb), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)bm, c_rows);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+// my rows of dI = G T / temp and of dT = G^T I / temp from the gathered statistics r_all, c_all ([B] each); gv_out (device scalar
+// or null) = sum over my image rows and all columns of G v (this rank's part of the temperature gradient)
+int sc_pair_contrastive_rows_grad(const float* img, const float* txt, int64_t b, int64_t e, int64_t row0, int64_t bm, float inv_temp, float grad_scale,
+                                  const float* r_all, const float* c_all, float* d_img_rows, float* d_txt_rows, float* gv_out, void* ws, hipStream_t st) {
+    PairWs w;
+    pair_carve(ws, b, e, w);
+    split_launch(img, b, e, w.xh, w.xl, w.xth, w.xtl, st);
+    split_launch(txt, b, e, w.yh, w.yl, w.yth, w.ytl, st);
+    PairParams p = {};
+    p.Bi = (int)bm; p.Bj = (int)b; p.E = (int)e; p.inv_temp = inv_temp; p.diag_off = (int)row0;
+    p.nsplit = pair_nsplit_rows(bm, b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
+    p.coef_row = p.coef_col = grad_scale / (2.f * (float)b); p.coef_diag = grad_scale / (float)b;
+    p.opart = w.opart; p.scal_part = w.scal_part;
+    const int64_t n = bm * e;
+    const unsigned rb = (unsigned)sc_cdiv(n / 4, 256);
+    p.xh = w.xh + row0 * e; p.xl = w.xl + row0 * e; p.yh = w.yh; p.yl = w.yl; p.zth = w.yth; p.ztl = w.ytl; p.rowv = r_all + row0; p.colv = c_all;
+    SC_TRY(pair_launch<PM_CON_GRAD>(p, st));
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(rb), dim3(256), 0, st, w.opart, p.nsplit, n, inv_temp, d_img_rows);
+    if (gv_out) hipLaunchKernelGGL(sum_scalar_kernel, dim3(1), dim3(256), 0, st, w.scal_part, (int)(bm / PT) * p.nsplit, 1.f, gv_out);
+    p.xh = w.yh + row0 * e; p.xl = w.yl + row0 * e; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl; p.rowv = c_all + row0; p.colv = r_all;
+    SC_TRY(pair_launch<PM_CON_GRAD>(p, st));
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(rb), dim3(256), 0, st, w.opart, p.nsplit, n, inv_temp, d_txt_rows);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+// lunif: my rows of the row sums of W and of W X
+int sc_pair_lunif_rows(const float* x, const float* sumsq, int64_t b, int64_t e, int64_t row0, int64_t bm, float t, float* rowsum_rows, float* wx_rows,
+                       void* ws, hipStream_t st) {
+    PairWs w;
+    pair_carve(ws, b, e, w);
+    split_launch(x, b, e, w.xh, w.xl, w.xth, w.xtl, st);
+    PairParams p = {};
+    p.Bi = (int)bm; p.Bj = (int)b; p.E = (int)e; p.t = t; p.diag_off = (int)row0;
+    p.nsplit = pair_nsplit_rows(bm, b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
+    p.xh = w.xh + row0 * e; p.xl = w.xl + row0 * e; p.yh = w.xh; p.yl = w.xl; p.zth = w.xth; p.ztl = w.xtl;
+    p.rowv = sumsq + row0; p.colv = sumsq; p.opart = w.opart; p.spart = w.spart; p.scal_part = w.scal_part;
+    SC_TRY(pair_launch<PM_UNIF>(p, st));
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)sc_cdiv(bm * e / 4, 256)), dim3(256), 0, st, w.opart, p.nsplit, bm * e, 1.f, wx_rows);
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)sc_cdiv(bm / 4, 256)), dim3(256), 0, st, w.spart, p.nsplit, bm, 1.f, rowsum_rows);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}

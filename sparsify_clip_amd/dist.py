@@ -120,6 +120,34 @@ def all_gather_embeddings(img_local: torch.Tensor, txt_local: torch.Tensor):
     return recv[:, 0].reshape(w * bl, e), recv[:, 1].reshape(w * bl, e)   # reshape of a strided view = the one copy
 
 
+def sharding():
+    """(world, rank) of the loss-head sharding: the process group's, or the bench's simulated world (rank 0), or (1, 0)."""
+    if active():
+        return world_size(), get_rank()
+    return (_sim["world"], 0) if _sim["world"] > 1 else (1, 0)
+
+
+def exchange_packets(packet: torch.Tensor) -> torch.Tensor:
+    """The one collective of the sharded loss head: every rank's statistics packet [P] -> [world, P] (rank-major)."""
+    if not active():
+        w = _sim["world"]
+        return packet.unsqueeze(0).expand(w, -1).contiguous() if w > 1 else packet.unsqueeze(0)     # bench only: filler = copies of rank 0's
+    w = world_size()
+    if dist.get_backend() == "gloo" and packet.is_cuda:   # rehearsal path only
+        parts = [torch.empty_like(packet) for _ in range(w)]
+        dist.all_gather(parts, packet)
+        return torch.stack(parts, dim=0)
+    out = torch.empty(w, packet.numel(), dtype=packet.dtype, device=packet.device)
+    dist.all_gather_into_tensor(out.view(-1), packet)
+    return out
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if active():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def local_rows(full: torch.Tensor):
     """This rank's rows of a gathered [B,E] tensor (the backward of the gather needs no collective)."""
     if not active():

@@ -108,3 +108,85 @@ def step_loss(config, image_embeds, text_embeds, temperature, epoch, current_bat
             ops.centroid_bwd_accumulate(c, inv, dc, d_img, d_txt)
             terms["lunif_centroids"] = lc
     return StepLoss(total, d_img, d_txt, d_temp, beta, alpha, terms)
+
+
+def step_loss_rows(config, image_embeds, text_embeds, temperature, epoch, current_batch, t_total, row0, rows, exchange, want_dtemp=False) -> StepLoss:
+    """step_loss for a rank that owns rows [row0, row0 + rows) of the gathered batch (equal shards, rank-major): the O(B^2) terms
+    visit this rank's rows x all columns only (world times less work than the replicated loss head), every rank obtains the same
+    loss value, and d_img / d_txt are THIS RANK'S ROWS of the gradients ([rows, E]).  `exchange(packet [P]) -> [world, P]` is the
+    one collective: every rank's row / column LSE, diagonal logits and the three scalars the other terms need.  d_temp is this rank's
+    part (SUM over ranks gives the gradient).  Same arithmetic per element as step_loss; the value differs from the replicated one
+    only by fp32 summation order."""
+    spec = validate_loss_type(config["loss_type"])
+    dev = image_embeds.device
+    b, e = image_embeds.shape
+    a, z = row0, row0 + rows
+    total = torch.zeros(1, dtype=torch.float32, device=dev)
+    terms = {}
+    share = rows / b
+    warm = spec.warmup_phase and epoch < config["only_lunif_epochs"]
+    beta = alpha = None
+    w_la = w_un = 1.0
+    if not warm:
+        if spec.use_lalign and spec.use_alpha:
+            alpha = w_la = get_alpha(current_batch, t_total, config["alpha_warmup_epoch"], config["alpha_increment_epoch"])
+        if spec.unif != "none" and spec.use_beta:
+            beta = w_un = get_beta(current_batch, t_total, config["beta_warmup_epoch"], config["beta_decay_epoch"])
+    # ---- phase 1: this rank's statistics
+    packet = torch.zeros(3 * rows + 3, dtype=torch.float32, device=dev)
+    unif_inputs = []     # (name, x_all, weight, rowsum, wx, slot in the packet)
+    if warm or spec.unif == "both":
+        unif_inputs = [("lunif_img", image_embeds, 0.5 * w_un), ("lunif_txt", text_embeds, 0.5 * w_un)]
+    elif spec.unif == "centroids":
+        c, inv = ops.centroid_fwd(image_embeds, text_embeds)          # all rows: O(B E), every rank needs every centroid as a column
+        unif_inputs = [("lunif_centroids", c, w_un)]
+    if not warm:
+        packet[: 3 * rows].copy_(ops.contrastive_rows_stats(image_embeds, text_embeds, row0, rows, temperature).reshape(-1))
+    unif_state = []
+    for k, (name, x, w) in enumerate(unif_inputs):
+        rowsum, wx, s_part = ops.lunif_rows_stats(x, row0, rows, 2.0)
+        packet[3 * rows + k: 3 * rows + k + 1].copy_(s_part)
+        unif_state.append((name, x, w, rowsum, wx, 3 * rows + k))
+    d_img = d_txt = None
+    if not warm and spec.use_lalign:   # a sum over pairs: this rank's pairs, weighted by its share of the batch
+        la, d_img, d_txt = ops.lalign_fwd_bwd(image_embeds[a:z], text_embeds[a:z], 2.0, grad_scale=w_la * share)
+        packet[3 * rows + 2: 3 * rows + 3].copy_(la)
+    # ---- the one collective
+    packets = exchange(packet)                       # [world, P]
+    world = packets.shape[0]
+    # ---- phase 2: loss value (identical on every rank) and this rank's rows of the gradients
+    d_temp = None
+    if not warm:
+        r_all = packets[:, 0:rows].reshape(-1).contiguous()
+        c_all = packets[:, rows:2 * rows].reshape(-1).contiguous()
+        g_all = packets[:, 2 * rows:3 * rows].reshape(-1).contiguous()
+        anchor, gi, gt, d_temp = ops.contrastive_rows_grad(image_embeds, text_embeds, row0, rows, temperature, r_all, c_all, g_all, need_dtemp=want_dtemp)
+        ops.axpy_(total, 1.0, anchor)
+        terms["anchor"] = anchor
+        if d_img is None:
+            d_img, d_txt = gi, gt
+        else:
+            ops.axpy_(d_img, 1.0, gi)
+            ops.axpy_(d_txt, 1.0, gt)
+        if spec.use_lalign:
+            la_all = torch.zeros(1, dtype=torch.float32, device=dev)
+            for r in range(world):                   # fixed order: the same value on every rank
+                ops.axpy_(la_all, share, packets[r, 3 * rows + 2: 3 * rows + 3])
+            ops.axpy_(total, w_la, la_all)
+            terms["lalign"] = la_all
+    for name, x, w, rowsum, wx, slot in unif_state:
+        s_parts = packets[:, slot].contiguous()
+        lu, dx = ops.lunif_rows_grad(x[a:z], b, 2.0, w, s_parts, rowsum, wx)
+        ops.axpy_(total, w, lu)
+        terms[name] = lu
+        if name == "lunif_centroids":
+            if d_img is None:
+                d_img, d_txt = torch.zeros(rows, e, dtype=torch.float32, device=dev), torch.zeros(rows, e, dtype=torch.float32, device=dev)
+            ops.centroid_bwd_accumulate(x[a:z], inv[a:z], dx, d_img, d_txt)
+        else:
+            tgt = "img" if name == "lunif_img" else "txt"
+            if tgt == "img":
+                d_img = dx if d_img is None else ops.axpy_(d_img, 1.0, dx)
+            else:
+                d_txt = dx if d_txt is None else ops.axpy_(d_txt, 1.0, dx)
+    return StepLoss(total, d_img, d_txt, d_temp if not warm else None, beta, alpha, terms)

@@ -6,6 +6,7 @@ computes on the host and nothing falls back to torch when the library is missing
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -162,6 +163,58 @@ def sparsify_fwd_bwd(x, grad_scale=1.0, need_grad=True):
     dx = torch.empty_like(x) if need_grad else None
     LIB.call("sc_sparsify_fwd_bwd", ptr(x), b, e, float(grad_scale), ptr(loss), ptr(dx), ptr(ws), ws.numel(), stream_ptr())
     return loss, dx
+
+# ---- row-block ("sharded") forms: the rank owns rows [row0, row0 + bm) of the gathered batch (include/sparsify_hip.h)
+def loss_rows_supported(b, e, row0, bm) -> bool:
+    """Shapes the row-block loss head takes (otherwise the caller evaluates the replicated loss head)."""
+    return b % 64 == 0 and b >= 128 and e % 128 == 0 and 128 <= e <= 1024 and row0 % 64 == 0 and bm % 64 == 0 and bm >= 64 and row0 + bm <= b \
+        and os.environ.get("SC_LOSS_FUSED", "1") != "0"
+
+
+def contrastive_rows_stats(img, txt, row0, bm, temperature):
+    """-> stats [3, bm]: row LSE of my image rows, column LSE of my text columns, diagonal logits of my rows."""
+    require_gpu(img, "img", torch.float32), require_gpu(txt, "txt", torch.float32)
+    b, e = img.shape
+    ws = _loss_ws(b, e, img.device)
+    stats = torch.empty(3, bm, dtype=torch.float32, device=img.device)
+    LIB.call("sc_contrastive_rows_stats", ptr(img), ptr(txt), b, e, int(row0), int(bm), float(temperature), ptr(stats), ptr(ws), ws.numel(), stream_ptr())
+    return stats
+
+
+def contrastive_rows_grad(img, txt, row0, bm, temperature, row_lse, col_lse, diag, grad_scale=1.0, need_dtemp=False):
+    """row_lse / col_lse / diag: [B] gathered over the ranks.  -> loss [1], my rows of d_img / d_txt, my part of d_temp (or None)."""
+    b, e = img.shape
+    ws = _loss_ws(b, e, img.device)
+    loss = torch.empty(1, dtype=torch.float32, device=img.device)
+    d_img = torch.empty(bm, e, dtype=torch.float32, device=img.device)
+    d_txt = torch.empty(bm, e, dtype=torch.float32, device=img.device)
+    d_temp = torch.empty(1, dtype=torch.float32, device=img.device) if need_dtemp else None
+    LIB.call("sc_contrastive_rows_grad", ptr(img), ptr(txt), b, e, int(row0), int(bm), float(temperature), float(grad_scale), ptr(row_lse), ptr(col_lse),
+             ptr(diag), ptr(loss), ptr(d_img), ptr(d_txt), ptr(d_temp), ptr(ws), ws.numel(), stream_ptr())
+    return loss, d_img, d_txt, d_temp
+
+
+def lunif_rows_stats(x, row0, bm, t=2.0):
+    """-> my rows of the row sums of W [bm] and of W X [bm, e], and their sum s_part [1]."""
+    require_gpu(x, "x", torch.float32)
+    b, e = x.shape
+    ws = _loss_ws(b, e, x.device)
+    rowsum = torch.empty(bm, dtype=torch.float32, device=x.device)
+    wx = torch.empty(bm, e, dtype=torch.float32, device=x.device)
+    s_part = torch.empty(1, dtype=torch.float32, device=x.device)
+    LIB.call("sc_lunif_rows_stats", ptr(x), b, e, int(row0), int(bm), float(t), ptr(rowsum), ptr(wx), ptr(s_part), ptr(ws), ws.numel(), stream_ptr())
+    return rowsum, wx, s_part
+
+
+def lunif_rows_grad(x_rows, b, t, grad_scale, s_parts, rowsum, wx):
+    """s_parts: every rank's s_part [world].  -> loss [1] (identical on every rank), my rows of the gradient."""
+    bm, e = x_rows.shape
+    loss = torch.empty(1, dtype=torch.float32, device=x_rows.device)
+    dx = torch.empty_like(x_rows)
+    LIB.call("sc_lunif_rows_grad", ptr(x_rows), int(b), bm, e, float(t), float(grad_scale), ptr(s_parts), s_parts.numel(), ptr(rowsum), ptr(wx), ptr(loss),
+             ptr(dx), stream_ptr())
+    return loss, dx
+
 
 
 def l2norm_fwd(x, eps=0.0, out=None):

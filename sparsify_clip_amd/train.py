@@ -23,7 +23,7 @@ from . import ops
 from . import uniformity as U
 from ._lib import ScError
 from .data import SyntheticLoader, caption_length, get_tokenizer
-from .loss_dispatch import step_loss, validate_loss_type
+from .loss_dispatch import step_loss, step_loss_rows, validate_loss_type
 from .model import create_model_and_transforms
 from .optim import AdamW
 from .schedules import get_cosine_schedule_with_warmup
@@ -108,7 +108,16 @@ class Trainer:
         txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0, out=send[1])                     # :773
         img_all, txt_all = D.all_gather_embeddings(img_n, txt_n)
         temp = float(self.temperature.detach()) if self.learnable_t else float(self.temperature)
-        res = step_loss(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)   # :778-938
+        world, rank = D.sharding()
+        rows = img_all.shape[0] // world
+        sharded = world > 1 and cfg.get("shard_loss_head", True) and ops.loss_rows_supported(img_all.shape[0], img_all.shape[1], rank * rows, rows)
+        if sharded:   # this rank's rows x all columns of the O(B^2) terms; one small all-gather of LSE statistics in the middle
+            res = step_loss_rows(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, rank * rows, rows, D.exchange_packets,
+                                 want_dtemp=self.learnable_t)
+            if res.d_temp is not None:
+                D.all_reduce_sum_(res.d_temp)
+        else:
+            res = step_loss(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)   # :778-938
         if res.beta is not None:
             self.beta = res.beta
         if res.alpha is not None:
@@ -120,8 +129,8 @@ class Trainer:
             row.update(beta=self.beta, alpha=self.alpha)
         self.pending_logs.append((res.loss, row))
         self.optimizer.zero_grad()                                                 # :957
-        d_img_e = ops.l2norm_bwd(img_n, inv_i, D.local_rows(res.d_img))
-        d_txt_e = ops.l2norm_bwd(txt_n, inv_t, D.local_rows(res.d_txt))
+        d_img_e = ops.l2norm_bwd(img_n, inv_i, res.d_img if sharded else D.local_rows(res.d_img))
+        d_txt_e = ops.l2norm_bwd(txt_n, inv_t, res.d_txt if sharded else D.local_rows(res.d_txt))
         self.text_stream.wait_stream(main)          # loss.backward() (:965): the two towers' backward passes are independent too
         with torch.cuda.stream(self.text_stream):
             m.text_backward(d_txt_e)

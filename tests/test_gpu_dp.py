@@ -19,21 +19,23 @@ def _free_port():
     return p
 
 
-def _cfg():
+def _cfg(model="tiny", batch=8):
     from sparsify_clip_amd.config import finalize_config
-    return finalize_config({"project_name": "t", "run_name": "t", "seed": 42, "learning_rate": 1e-3, "batch_size": 8, "model": "tiny",
+    return finalize_config({"project_name": "t", "run_name": "t", "seed": 42, "learning_rate": 1e-3, "batch_size": batch, "model": model,
                             "num_train_samples": 64, "num_test_samples": 16, "epochs": 1,
                             "loss_type": "only_lunif_n_then_anchor+lalign+lunif(centroids)", "only_lunif_epochs": 0, "anchor_temperature": 0.1,
                             "anchor_temperature_learnable": False, "save_checkpoint_every_n_epochs": 20, "resume_checkpoint": False,
                             "fp16": False}, 0, {"precision": "fp32"})
 
 
-def _batches(steps):
+def _batches(steps, model="tiny", batch=8):
     from sparsify_clip_amd.data import synthetic_batch
-    return [synthetic_batch(300 + k, 8, 64, 16, 512) for k in range(steps)]
+    from sparsify_clip_amd.model import CONFIGS
+    c = CONFIGS[model]
+    return [synthetic_batch(300 + k, batch, c["image_size"], c["ctx"], c["vocab"]) for k in range(steps)]
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, model_name="tiny", batch=8):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       SC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     from sparsify_clip_amd import dist as D
@@ -41,27 +43,30 @@ def _run(rank, world, port, out):
     from sparsify_clip_amd.train import Trainer
     D.init_process_group()
     torch.cuda.set_device(0)
-    model = ClipModel("tiny", device="cuda:0", precision="fp32", seed=7 + rank)   # different init per rank: the broadcast must fix it
-    tr = Trainer(_cfg(), "cuda:0", 4, model=model)
+    model = ClipModel(model_name, device="cuda:0", precision="fp32", seed=7 + rank)   # different init per rank: the broadcast must fix it
+    tr = Trainer(_cfg(model_name, batch), "cuda:0", 4, model=model)
     losses = []
-    for images, tokens in _batches(3):
-        a, b = D.shard_bounds(8, rank, world)
+    for images, tokens in _batches(3, model_name, batch):
+        a, b = D.shard_bounds(batch, rank, world)
         losses.append(tr.step(images[a:b].cuda(), tokens[a:b].cuda()).item())
     out[rank] = (losses, model.param("visual.proj").cpu(), model.param("token_embedding.weight").cpu())
     torch.distributed.destroy_process_group()
 
 
-def test_dp2_step_equals_dp1_step():
+@pytest.mark.parametrize("model_name,batch", [("tiny", 8), ("test-small", 128)])
+def test_dp2_step_equals_dp1_step(model_name, batch):
+    """("test-small", 128): 64 pairs per rank and a 128-wide embedding - the shapes the SHARDED loss head takes (each rank its rows x
+    all columns, statistics exchanged through dist.exchange_packets); ("tiny", 8) runs the replicated loss head."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from sparsify_clip_amd.model import ClipModel
     from sparsify_clip_amd.train import Trainer
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
-    ref_model = ClipModel("tiny", device="cuda:0", precision="fp32", seed=7)     # rank 0's initialisation
-    tr = Trainer(_cfg(), "cuda:0", 4, model=ref_model)
-    want = [tr.step(i.cuda(), t.cuda()).item() for i, t in _batches(3)]
+    mp.spawn(_run, args=(2, _free_port(), out, model_name, batch), nprocs=2, join=True)
+    ref_model = ClipModel(model_name, device="cuda:0", precision="fp32", seed=7)     # rank 0's initialisation
+    tr = Trainer(_cfg(model_name, batch), "cuda:0", 4, model=ref_model)
+    want = [tr.step(i.cuda(), t.cuda()).item() for i, t in _batches(3, model_name, batch)]
     for rank in (0, 1):
         losses, proj, emb = out[rank]
         for got, w in zip(losses, want):

@@ -196,3 +196,56 @@ def test_full_state_sidecar_resume_is_bit_exact(gpu, tmp_path, monkeypatch):
     assert b_losses == full_losses[6:], (b_losses, full_losses)
     assert torch.equal(w_resumed, w_full)
     assert sd2.keys() == torch.load("models/sc2_epoch_4.pt", map_location="cpu", weights_only=True).keys()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_loss_head_equals_replicated(world):
+    """loss_dispatch.step_loss_rows (each rank: its rows x all columns of the O(B^2) terms, one exchange of LSE statistics) against
+    step_loss on the whole batch: same loss on every rank (1e-6), every rank's gradient rows equal the replicated rows (1e-5), the
+    ranks' d_temp parts add up - for the plain anchor, both uniformity forms, the alpha / beta schedules and the warm-up phase.
+    The ranks are emulated one after the other in this process: a first pass records every rank's packet, a second pass feeds
+    each rank the gathered packets (rank-major), exactly what dist.exchange_packets returns."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sparsify_clip_amd.loss_dispatch import step_loss, step_loss_rows
+    dev = "cuda:0"
+    b, e = 256, 512
+    g = torch.Generator().manual_seed(5)
+    centers = torch.nn.functional.normalize(torch.randn(16, e, generator=g), dim=-1)
+    idx = torch.randint(0, 16, (b,), generator=g)
+    img = torch.nn.functional.normalize(centers[idx] + 0.3 * torch.randn(b, e, generator=g), dim=-1).to(dev)
+    txt = torch.nn.functional.normalize(centers[idx] + 0.3 * torch.randn(b, e, generator=g), dim=-1).to(dev)
+    base = {"only_lunif_epochs": 1, "alpha_warmup_epoch": 1, "alpha_increment_epoch": 2, "beta_warmup_epoch": 1, "beta_decay_epoch": 3}
+    cases = [("anchor", 1), ("only_lunif_n_then_anchor+lalign+lunif(centroids)", 1), ("only_lunif_n_then_anchor+lalign+lunif(centroids)", 0),
+             ("only_lunif_n_then_anchor+ALPHA*lalign+BETA*(lunif(text)+lunif(img))", 1), ("ANCHOR(IMAGE,TEXT)+LUNIF(CENTROIDS)", 0),
+             ("only_lunif_n_then_anchor+ALPHA*lalign+BETA*lunif(centroids)", 2)]
+    rows = b // world
+    for loss_type, epoch in cases:
+        cfg = dict(base, loss_type=loss_type)
+        args = (0.07, epoch, 40, 100)
+        want = step_loss(cfg, img, txt, *args, want_dtemp=True)
+        packets = {}
+
+        def record(rank):
+            def f(p):
+                packets[rank] = p.clone()
+                return p.unsqueeze(0).expand(world, -1).contiguous()
+            return f
+        for r in range(world):
+            step_loss_rows(cfg, img, txt, *args, r * rows, rows, record(r), want_dtemp=True)
+        gathered = torch.stack([packets[r] for r in range(world)], dim=0)
+        dtemp = None
+        for r in range(world):
+            got = step_loss_rows(cfg, img, txt, *args, r * rows, rows, lambda p: gathered, want_dtemp=True)
+            a, z = r * rows, (r + 1) * rows
+            assert abs(got.loss.item() - want.loss.item()) <= 1e-6 * abs(want.loss.item()) + 1e-7, (loss_type, epoch, r)
+            for name in ("d_img", "d_txt"):
+                w_, g_ = getattr(want, name)[a:z].double(), getattr(got, name).double()
+                assert ((g_ - w_).norm() / w_.norm().clamp_min(1e-30)).item() < 1e-5, (loss_type, epoch, r, name)
+            assert got.beta == want.beta and got.alpha == want.alpha
+            assert (got.d_temp is None) == (want.d_temp is None)
+            if got.d_temp is not None:
+                dtemp = got.d_temp.clone() if dtemp is None else dtemp + got.d_temp
+        if want.d_temp is not None:
+            assert abs(dtemp.item() - want.d_temp.item()) <= 1e-5 * abs(want.d_temp.item()) + 1e-7, (loss_type, dtemp.item(), want.d_temp.item())
