@@ -315,6 +315,42 @@ int sc_image_resample_normalize(const uint8_t* src, const int64_t* offset, const
 int sc_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ModifiedResNet ("RN50", the `model:` of every reference YAML; open_clip ModifiedResNet / Bottleneck / AttentionPool2d behind
+ * sparsify_clip.py:685-689, :768).  Activations are NHWC = row-major [B*H*W, C] matrices in the compute dtype (SC_BF16 / SC_F32):
+ * a 1x1 convolution is sc_gemm_*_nt as it stands, a 3x3 convolution is sc_im2col3x3 + the same GEMM, its input gradient the GEMM
+ * against the transposed weight + sc_col2im3x3, its weight gradient sc_gemm_*_tn.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[(b,yo,xo)][tap*C + c] = x[b][yo*stride+ky-1][xo*stride+kx-1][c] (tap = 3ky+kx, zero padding, columns >= 9C zero; kpad >= 9C).
+ * in_nchw_f32 != 0: x is the fp32 image tensor [B,C,H,W] (stem), else an NHWC activation of `dtype`.  out is `dtype`. */
+int sc_im2col3x3(const void* x, int in_nchw_f32, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t stride, int64_t kpad,
+                 void* out, void* stream);
+int sc_col2im3x3(const void* dcols, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t stride, int64_t kpad, void* dx, void* stream);
+/* nn.AvgPool2d(k) (k = stride; h, w multiples of k) and its backward */
+int sc_avgpool_fwd(const void* x, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t k, void* y, void* stream);
+int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t k, void* dx, void* stream);
+/* nn.BatchNorm2d in training mode over x [rows, c].  sc_bn_stats: this rank's shifted sums stats[3c] (sum(x-k), sum (x-k)^2, k);
+ * sc_bn_finish: from nparts such triples of rows_per_part rows each (1 part without data parallelism; the gathered triples of all
+ * ranks for a synchronised BatchNorm) the batch mean and 1/sqrt(biased var + eps), and the running statistics update of torch
+ * (momentum, unbiased variance; NULL skips it).  sc_bn_apply: y = act((x-mean)*rstd*gamma + beta (+ res)), act = ReLU if relu.
+ * Backward: sc_bn_bwd_stats gives sums[2c] = sum g | sum g*xhat over this rank's rows (g = dy masked by y > 0 if relu; SUM them over
+ * ranks for a synchronised BatchNorm); sc_bn_bwd_apply writes dx, optionally dres = g (the gradient of the residual input),
+ * and dgamma / dbeta (+= if accumulate) from `sums` with total_rows = rows of the whole batch. */
+size_t sc_bn_workspace_bytes(int64_t rows, int64_t c);
+int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, float* stats, void* ws, size_t ws_bytes, void* stream);
+int sc_bn_finish(const float* stats, int64_t nparts, int64_t c, int64_t rows_per_part, float eps, float momentum, float* mean, float* rstd,
+                 float* running_mean, float* running_var, void* stream);
+int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                const void* res, int relu, void* y, void* stream);
+int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
+                    int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
+int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
+                    const float* gamma, const float* sums, int64_t total_rows, int relu, int accumulate, void* dx, void* dres, float* dgamma,
+                    float* dbeta, void* stream);
+/* AttentionPool2d token assembly: tokens[b][0] = mean_p x[b][p] + pos[0], tokens[b][p+1] = x[b][p] + pos[p+1]; backward w.r.t. x */
+int sc_attnpool_tokens_fwd(const void* x, int dtype, const float* pos, int64_t batch, int64_t hw, int64_t c, void* tokens, void* stream);
+int sc_attnpool_tokens_bwd(const void* dtokens, int dtype, int64_t batch, int64_t hw, int64_t c, void* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

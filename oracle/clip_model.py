@@ -21,7 +21,15 @@ CONFIGS = {
                      ctx=77, vocab=49408, t_width=512, t_layers=12, t_heads=8),
     "ViT-L-14": dict(embed_dim=768, image_size=224, patch=14, v_width=1024, v_layers=24, v_heads=16,
                      ctx=77, vocab=49408, t_width=768, t_layers=12, t_heads=12),
+    # open_clip "RN50": ModifiedResNet (three-conv stem, anti-aliasing average pools, attention pooling) + the 512-wide text tower.
+    # This is the `model:` every shipped reference YAML names.  v_layers = bottlenecks per stage, v_width = stem width.
+    "RN50": dict(embed_dim=1024, image_size=224, v_kind="resnet", v_layers=(3, 4, 6, 3), v_width=64,
+                 ctx=77, vocab=49408, t_width=512, t_layers=12, t_heads=8),
     # small shapes for tests (same architecture, not an open_clip config)
+    "test-rn": dict(embed_dim=64, image_size=64, v_kind="resnet", v_layers=(1, 2, 1, 1), v_width=16,
+                    ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
+    "test-rn64": dict(embed_dim=128, image_size=64, v_kind="resnet", v_layers=(1, 1, 1, 1), v_width=128,
+                      ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
     "tiny": dict(embed_dim=64, image_size=64, patch=32, v_width=128, v_layers=2, v_heads=2,
                  ctx=16, vocab=512, t_width=64, t_layers=2, t_heads=1),
     "test-small": dict(embed_dim=128, image_size=224, patch=32, v_width=128, v_layers=1, v_heads=2,
@@ -89,12 +97,108 @@ class VisionTransformer(nn.Module):
         return x[:, 0] @ self.proj
 
 
+class Bottleneck(nn.Module):
+    """open_clip ModifiedResNet bottleneck: 1x1 - 3x3 - (average pool for the stride) - 1x1, all convolutions at stride 1;
+    the shortcut is average pool + 1x1 convolution when the shape changes."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(OrderedDict([("-1", nn.AvgPool2d(stride)), ("0", nn.Conv2d(inplanes, planes * 4, 1, bias=False)),
+                                                         ("1", nn.BatchNorm2d(planes * 4))]))
+
+    def forward(self, x):
+        out = torch.relu(self.bn1(self.conv1(x)))
+        out = torch.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(self.avgpool(out)))
+        identity = x if self.downsample is None else self.downsample(x)
+        return torch.relu(out + identity)
+
+
+class AttentionPool2d(nn.Module):
+    """QKV attention over the HW feature positions plus their mean; the output is the attended mean token."""
+
+    def __init__(self, spacial_dim, embed_dim, num_heads, output_dim):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.c_proj = nn.Linear(embed_dim, output_dim)
+        self.num_heads = num_heads
+
+    def forward(self, x):
+        b, c = x.shape[0], x.shape[1]
+        x = x.reshape(b, c, -1).permute(0, 2, 1)                               # [B, HW, C]
+        x = torch.cat([x.mean(dim=1, keepdim=True), x], dim=1) + self.positional_embedding
+        hd = c // self.num_heads
+        q = self.q_proj(x[:, :1]).reshape(b, 1, self.num_heads, hd).transpose(1, 2)
+        k = self.k_proj(x).reshape(b, -1, self.num_heads, hd).transpose(1, 2)
+        v = self.v_proj(x).reshape(b, -1, self.num_heads, hd).transpose(1, 2)
+        att = torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1)
+        return self.c_proj((att @ v).transpose(1, 2).reshape(b, c))
+
+
+class ModifiedResNet(nn.Module):
+    def __init__(self, layers, output_dim, heads, image_size, width):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width // 2, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width // 2)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width // 2)
+        self.conv3 = nn.Conv2d(width // 2, width, 3, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width)
+        self.avgpool = nn.AvgPool2d(2)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0])
+        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
+        self.attnpool = AttentionPool2d(image_size // 32, width * 32, heads, output_dim)
+        self._init()
+
+    def _make_layer(self, planes, blocks, stride=1):
+        layers = [Bottleneck(self._inplanes, planes, stride)]
+        self._inplanes = planes * 4
+        layers += [Bottleneck(self._inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def _init(self):     # open_clip ModifiedResNet.init_parameters
+        std = self.attnpool.c_proj.in_features ** -0.5
+        for proj in (self.attnpool.q_proj, self.attnpool.k_proj, self.attnpool.v_proj, self.attnpool.c_proj):
+            nn.init.normal_(proj.weight, std=std)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for name, param in layer.named_parameters():
+                if name.endswith("bn3.weight"):
+                    nn.init.zeros_(param)
+
+    def forward(self, x):
+        x = torch.relu(self.bn1(self.conv1(x)))
+        x = torch.relu(self.bn2(self.conv2(x)))
+        x = torch.relu(self.bn3(self.conv3(x)))
+        x = self.avgpool(x)
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.attnpool(x)
+
+
 class CLIP(nn.Module):
     def __init__(self, name="ViT-B-32"):
         super().__init__()
         c = CONFIGS[canonical_name(name)]
         self.cfg = c
-        self.visual = VisionTransformer(c["image_size"], c["patch"], c["v_width"], c["v_layers"], c["v_heads"], c["embed_dim"])
+        if c.get("v_kind") == "resnet":
+            self.visual = ModifiedResNet(c["v_layers"], c["embed_dim"], c["v_width"] * 32 // 64, c["image_size"], c["v_width"])
+        else:
+            self.visual = VisionTransformer(c["image_size"], c["patch"], c["v_width"], c["v_layers"], c["v_heads"], c["embed_dim"])
         self.transformer = Transformer(c["t_width"], c["t_layers"], c["t_heads"])
         self.token_embedding = nn.Embedding(c["vocab"], c["t_width"])
         self.positional_embedding = nn.Parameter(torch.empty(c["ctx"], c["t_width"]))

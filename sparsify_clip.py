@@ -3,9 +3,8 @@
 
     python sparsify_clip.py --config <yaml file | directory of yaml files> --device <gpu id>
 
-Every experiments_configs/*.yaml and ablatation_configs/*.yaml of the reference is read unchanged, but all of them say
-model "RN50" (ModifiedResNet), which is not implemented natively: without `--model ViT-B-32` (or ViT-L-14) such a file
-is rejected at load time with a message naming that override.  The optional overrides select the ViT configurations and
+Every experiments_configs/*.yaml and ablatation_configs/*.yaml of the reference is read and run unchanged (they all say model
+"RN50": the ModifiedResNet-50 tower of sparsify_clip_amd/resnet.py).  The optional overrides select the ViT configurations and
 batch sizes of BASELINE.json without editing the files.  Under torchrun (WORLD_SIZE > 1) the run is data-parallel over the node's GPUs and --device is
 replaced by LOCAL_RANK.  The loss/schedule functions of the reference are importable from this module by name.
 """
@@ -28,7 +27,7 @@ def parse_args(argv=None):
     p.add_argument("--config", type=str, required=True, help="Path to the yaml config file or to a folder containing multiple config files")
     p.add_argument("--device", type=int, required=True, help="GPU id to use")
     # optional overrides on top of the unchanged YAML (default: use the YAML's value)
-    p.add_argument("--model", type=str, default=None, help="e.g. ViT-B-32, ViT-L-14 (the YAMLs say RN50, which is not implemented natively)")
+    p.add_argument("--model", type=str, default=None, help="RN50 (what the YAMLs say), ViT-B-32, ViT-L-14")
     p.add_argument("--batch-size", type=int, default=None, help="global batch size")
     p.add_argument("--epochs", type=int, default=None)
     p.add_argument("--num-train-samples", type=int, default=None)

@@ -2,9 +2,8 @@
 
 The reference reads a YAML into a dict and passes it everywhere (sparsify_clip.py:1134-1156): `learning_rate`
 arrives as a string ("1e-4") and is float()-ed (:1141), `device_id` is injected (:1139).  Every shipped YAML says
-model "RN50", batch 256, fp16 True; RN50 (ModifiedResNet) is NOT implemented here, so a reference YAML is rejected at load
-time with a message naming the `--model ViT-B-32|ViT-L-14` override; with that override (and the other optional ones for
-the BASELINE batch sizes) the file itself stays unchanged.
+model "RN50", batch 256, fp16 True: the files run as they are (ModifiedResNet-50 image tower: resnet.py); `--model ViT-B-32|ViT-L-14`
+and the other optional overrides select the BASELINE configurations without editing a file.
 """
 from __future__ import annotations
 
@@ -45,10 +44,8 @@ def finalize_config(cfg: dict, device_id: int = 0, overrides: dict | None = None
         raise ScError(f"config is missing keys {missing}")
     from .model import CONFIGS, canonical_name
     if canonical_name(str(cfg["model"])) not in CONFIGS:
-        # every shipped YAML says model: "RN50" (open_clip ModifiedResNet), which this build does not implement natively
-        raise ScError(f"config model {cfg['model']!r} is not implemented natively; implemented: {sorted(CONFIGS)}. The reference YAMLs "
-                      "(all 'RN50') run unchanged once the tower is named on the command line: "
-                      "`python sparsify_clip.py --config <yaml> --device 0 --model ViT-B-32` (or ViT-L-14)")
+        raise ScError(f"config model {cfg['model']!r} is not implemented natively; implemented: {sorted(CONFIGS)} "
+                      "(RN50, the model of every reference YAML, ViT-B-32 and ViT-L-14; override with --model)")
     cfg["device_id"] = device_id                       # :1139
     cfg["learning_rate"] = float(cfg["learning_rate"])  # :1141
     spec = validate_loss_type(cfg["loss_type"])

@@ -3,8 +3,10 @@ torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" runs the same bookkeep
 
 The reference is single-process (its nn.DataParallel wrapper is bypassed), so nothing here is a
 translation.  Partition: the global batch is cut rank-major into contiguous slices; each rank encodes its slice,
-the L2-normalised embeddings are all-gathered (one fused [Bl, 2E] message per rank), every rank evaluates the
-identical global-batch loss head and keeps rows [r*Bl, (r+1)*Bl) of dL/dI and dL/dT.  Parameter gradients are
+the L2-normalised embeddings are all-gathered (one fused [2, Bl, E] message per rank); the global-batch loss head is evaluated
+by rows: rank r runs the O(B^2) sweeps over rows [r*Bl, (r+1)*Bl) against every column, the ranks exchange their LSE statistics
+once (exchange_packets), and each rank ends with the same loss value and its own rows of dL/dI and dL/dT (shapes the row-block
+kernels do not take fall back to every rank evaluating the whole loss head and keeping its rows).  Parameter gradients are
 all-reduced with SUM (the loss already carries its 1/B factors) bucket by bucket as the backward produces them,
 on RCCL's own stream, and joined before the optimiser step.
 """

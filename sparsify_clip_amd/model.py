@@ -31,6 +31,13 @@ CONFIGS = {
                      ctx=77, vocab=49408, t_width=512, t_layers=12, t_heads=8),
     "ViT-L-14": dict(embed_dim=768, image_size=224, patch=14, v_width=1024, v_layers=24, v_heads=16,
                      ctx=77, vocab=49408, t_width=768, t_layers=12, t_heads=12),
+    # open_clip "RN50" (the `model:` of every reference YAML): ModifiedResNet image tower (resnet.py) + the 512-wide text tower
+    "RN50": dict(embed_dim=1024, image_size=224, v_kind="resnet", v_layers=(3, 4, 6, 3), v_width=64,
+                 ctx=77, vocab=49408, t_width=512, t_layers=12, t_heads=8),
+    "test-rn": dict(embed_dim=64, image_size=64, v_kind="resnet", v_layers=(1, 2, 1, 1), v_width=16,
+                    ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
+    "test-rn64": dict(embed_dim=128, image_size=64, v_kind="resnet", v_layers=(1, 1, 1, 1), v_width=128,
+                      ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
     "tiny": dict(embed_dim=64, image_size=64, patch=32, v_width=128, v_layers=2, v_heads=2,
                  ctx=16, vocab=512, t_width=64, t_layers=2, t_heads=1),
     "test-small": dict(embed_dim=128, image_size=224, patch=32, v_width=128, v_layers=1, v_heads=2,
@@ -79,8 +86,7 @@ class ClipModel:
     def __init__(self, name="ViT-B-32", device="cuda:0", precision="bf16", seed=0):
         cname = canonical_name(name)
         if cname not in CONFIGS:
-            raise ScError(f"model {name!r} is not implemented natively (ViT-B-32, ViT-L-14 and 'tiny' are); "
-                          "RN50 (ModifiedResNet) is out of scope, see DESIGN.md")
+            raise ScError(f"model {name!r} is not implemented natively (RN50, ViT-B-32, ViT-L-14 and the test geometries are)")
         self.name, self.cfg = cname, CONFIGS[cname]
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -90,10 +96,17 @@ class ClipModel:
         self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
         self.training = True
         c = self.cfg
-        self.grid = c["image_size"] // c["patch"]
-        self.k_patch = 3 * c["patch"] ** 2
-        self.k_pad = ((self.k_patch + 63) // 64) * 64
-        self.visual = _Tower("image", "visual.transformer.resblocks.", c["v_width"], c["v_layers"], c["v_heads"], self.grid ** 2 + 1, 0)
+        self.buffers = {}     # non-trainable state that belongs in the state_dict (BatchNorm running statistics of the ResNet tower)
+        self.rn = None
+        if c.get("v_kind") == "resnet":
+            from .resnet import ResNetVisual
+            self.rn = ResNetVisual(self, c)
+            self.visual = None
+        else:
+            self.grid = c["image_size"] // c["patch"]
+            self.k_patch = 3 * c["patch"] ** 2
+            self.k_pad = ((self.k_patch + 63) // 64) * 64
+            self.visual = _Tower("image", "visual.transformer.resblocks.", c["v_width"], c["v_layers"], c["v_heads"], self.grid ** 2 + 1, 0)
         self.text = _Tower("text", "transformer.resblocks.", c["t_width"], c["t_layers"], c["t_heads"], c["ctx"], 1)
         self._layout()
         self.flat = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
@@ -106,6 +119,9 @@ class ClipModel:
         self._aux_stream, self.wt_ready = None, None
         self._side = None      # side stream of the weight-gradient GEMMs (bf16 path)
         self._wt_batch = None  # batched launcher of the [in,out] weight copies
+        if self.rn is not None:
+            for bname, shape, fill, bdt in self.rn.buffer_specs():
+                self.buffers[bname] = torch.full(shape, fill, dtype=bdt, device=self.device)
         self.init_parameters(seed)
 
     # ------------------------------------------------------------------------------------------ layout
@@ -114,11 +130,14 @@ class ClipModel:
         order = []
         vw, tw, e = c["v_width"], c["t_width"], c["embed_dim"]
         # image tower: head, blocks L-1..0, stem
-        order += [("visual.ln_post.weight", (vw,)), ("visual.ln_post.bias", (vw,)), ("visual.proj", (vw, e))]
-        for i in reversed(range(c["v_layers"])):
-            order += [(f"visual.transformer.resblocks.{i}.{k}", s) for k, s in _block_shapes(vw).items()]
-        order += [("visual.ln_pre.weight", (vw,)), ("visual.ln_pre.bias", (vw,)), ("visual.positional_embedding", (self.grid ** 2 + 1, vw)),
-                  ("visual.class_embedding", (vw,)), ("visual.conv1.weight", (vw, 3, c["patch"], c["patch"]))]
+        if self.rn is not None:
+            order += self.rn.param_order()
+        else:
+            order += [("visual.ln_post.weight", (vw,)), ("visual.ln_post.bias", (vw,)), ("visual.proj", (vw, e))]
+            for i in reversed(range(c["v_layers"])):
+                order += [(f"visual.transformer.resblocks.{i}.{k}", s) for k, s in _block_shapes(vw).items()]
+            order += [("visual.ln_pre.weight", (vw,)), ("visual.ln_pre.bias", (vw,)), ("visual.positional_embedding", (self.grid ** 2 + 1, vw)),
+                      ("visual.class_embedding", (vw,)), ("visual.conv1.weight", (vw, 3, c["patch"], c["patch"]))]
         # text tower
         order += [("ln_final.weight", (tw,)), ("ln_final.bias", (tw,)), ("text_projection", (tw, e))]
         for i in reversed(range(c["t_layers"])):
@@ -144,11 +163,15 @@ class ClipModel:
             o, s = self.slots[last]
             return (a, o + ((math.prod(s) + 63) // 64) * 64)
 
-        self.buckets.append(("visual.head", span("visual.ln_post.weight", "visual.proj")))
-        for i in reversed(range(c["v_layers"])):
-            p = f"visual.transformer.resblocks.{i}."
-            self.buckets.append((p, span(p + BLOCK_PARAMS[0], p + BLOCK_PARAMS[-1])))
-        self.buckets.append(("visual.stem", span("visual.ln_pre.weight", "visual.conv1.weight")))
+        if self.rn is not None:
+            for bname, first, last in self.rn.bucket_names():
+                self.buckets.append((bname, span(first, last)))
+        else:
+            self.buckets.append(("visual.head", span("visual.ln_post.weight", "visual.proj")))
+            for i in reversed(range(c["v_layers"])):
+                p = f"visual.transformer.resblocks.{i}."
+                self.buckets.append((p, span(p + BLOCK_PARAMS[0], p + BLOCK_PARAMS[-1])))
+            self.buckets.append(("visual.stem", span("visual.ln_pre.weight", "visual.conv1.weight")))
         self.buckets.append(("text.head", span("ln_final.weight", "text_projection")))
         for i in reversed(range(c["t_layers"])):
             p = f"transformer.resblocks.{i}."
@@ -185,6 +208,29 @@ class ClipModel:
 
         sd = {}
         vw, tw = c["v_width"], c["t_width"]
+        if self.rn is not None:
+            self.rn.init_parameters(sd, g)
+            sd["ln_final.weight"], sd["ln_final.bias"] = torch.ones(tw), torch.zeros(tw)
+        else:
+            self._init_vit_visual(sd, normal, uniform)
+        sd["token_embedding.weight"] = normal((c["vocab"], tw), 0.02)
+        sd["positional_embedding"] = normal((c["ctx"], tw), 0.01)
+        proj_std, attn_std, fc_std = (tw ** -0.5) * ((2 * c["t_layers"]) ** -0.5), tw ** -0.5, (2 * tw) ** -0.5
+        for i in range(c["t_layers"]):
+            p = f"transformer.resblocks.{i}."
+            sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"] = normal((3 * tw, tw), attn_std), torch.zeros(3 * tw)
+            sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"] = normal((tw, tw), proj_std), torch.zeros(tw)
+            sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = normal((4 * tw, tw), fc_std), uniform((4 * tw,), 1 / math.sqrt(tw))
+            sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = normal((tw, 4 * tw), proj_std), uniform((tw,), 1 / math.sqrt(4 * tw))
+            for ln in ["ln_1", "ln_2"]:
+                sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(tw), torch.zeros(tw)
+        sd["text_projection"] = normal((tw, c["embed_dim"]), tw ** -0.5)
+        sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
+        self.load_state_dict(sd)
+
+    def _init_vit_visual(self, sd, normal, uniform):
+        c = self.cfg
+        vw, tw = c["v_width"], c["t_width"]
         sd["visual.class_embedding"] = normal((vw,), vw ** -0.5)
         sd["visual.positional_embedding"] = normal((self.grid ** 2 + 1, vw), vw ** -0.5)
         sd["visual.proj"] = normal((vw, c["embed_dim"]), vw ** -0.5)
@@ -203,20 +249,6 @@ class ClipModel:
             sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = uniform((vw, 4 * vw), 1 / math.sqrt(4 * vw)), uniform((vw,), 1 / math.sqrt(4 * vw))
             for ln in ["ln_1", "ln_2"]:
                 sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(vw), torch.zeros(vw)
-        sd["token_embedding.weight"] = normal((c["vocab"], tw), 0.02)
-        sd["positional_embedding"] = normal((c["ctx"], tw), 0.01)
-        proj_std, attn_std, fc_std = (tw ** -0.5) * ((2 * c["t_layers"]) ** -0.5), tw ** -0.5, (2 * tw) ** -0.5
-        for i in range(c["t_layers"]):
-            p = f"transformer.resblocks.{i}."
-            sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"] = normal((3 * tw, tw), attn_std), torch.zeros(3 * tw)
-            sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"] = normal((tw, tw), proj_std), torch.zeros(tw)
-            sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = normal((4 * tw, tw), fc_std), uniform((4 * tw,), 1 / math.sqrt(tw))
-            sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = normal((tw, 4 * tw), proj_std), uniform((tw,), 1 / math.sqrt(4 * tw))
-            for ln in ["ln_1", "ln_2"]:
-                sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(tw), torch.zeros(tw)
-        sd["text_projection"] = normal((tw, c["embed_dim"]), tw ** -0.5)
-        sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
-        self.load_state_dict(sd)
 
     def named_parameters(self):
         for name in self.slots:
@@ -227,12 +259,18 @@ class ClipModel:
 
     def state_dict(self, prefix=""):
         """Flat {open_clip key: tensor}; pass prefix='module.' for the reference's DataParallel checkpoints (:983, :1118)."""
-        return OrderedDict((prefix + n, p.detach().clone()) for n, p in self.named_parameters())
+        sd = OrderedDict((prefix + n, p.detach().clone()) for n, p in self.named_parameters())
+        for n, b in self.buffers.items():
+            sd[prefix + n] = b.detach().clone()
+        return sd
 
     def load_state_dict(self, sd, strict=True):
         seen = set()
         for key, val in sd.items():
             name = key[len("module."):] if key.startswith("module.") else key
+            if name in self.buffers:
+                self.buffers[name].copy_(val.to(device=self.device, dtype=self.buffers[name].dtype))
+                continue
             if name not in self.slots:
                 if strict:
                     raise ScError(f"unexpected key {key!r} in state_dict")
@@ -263,6 +301,8 @@ class ClipModel:
         `overlap`: the ~100 small transposes are only read by the NEXT backward pass, so they go to an auxiliary stream (ordered
         behind everything enqueued so far) and run under the next forward pass; `_blocks_bwd` and the next optimiser step wait
         for `wt_ready`."""
+        if self.rn is not None:
+            self.rn.refresh_weights()      # GEMM-layout copies of the convolution weights (both precisions)
         if self.flat_bf16 is None:
             return
         if full:
@@ -288,6 +328,8 @@ class ClipModel:
         if self._wt_batch is None:
             pairs = []
             for tower in (self.visual, self.text):
+                if tower is None:
+                    continue
                 for i in range(tower.layers):
                     for k in GEMM_WEIGHTS:
                         name = f"{tower.prefix}{i}.{k}"
@@ -370,6 +412,8 @@ class ClipModel:
 
     def _bind_scratch(self):
         for tower in (self.visual, self.text):
+            if tower is None or not tower.descs:
+                continue
             tower.trimmed = {}
             for i, d in enumerate(tower.descs):
                 k = (tower.layers - 1 - i) % 2          # position in the backward order selects the scratch set
@@ -459,6 +503,8 @@ class ClipModel:
         if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != c["image_size"] or images.shape[3] != c["image_size"]:
             raise ScError(f"encode_image expects [B,3,{c['image_size']},{c['image_size']}], got {tuple(images.shape)}")
         images = images.to(device=self.device, dtype=torch.float32).contiguous()
+        if self.rn is not None:
+            return self.rn.forward(images)
         batch = images.shape[0]
         self._prepare(tw, batch)
         b = tw.bufs
@@ -483,6 +529,9 @@ class ClipModel:
         return padded
 
     def image_backward(self, d_emb):
+        if self.rn is not None:
+            self.wait_wt()
+            return self.rn.backward(d_emb, not self._grads_fresh_for("image"))
         tw, b = self.visual, self.visual.bufs
         acc = not self._grads_fresh_for("image")
         batch = tw.batch

@@ -441,3 +441,90 @@ def block_bwd(desc: BlockDesc, dx_out, dx_out_t, dx_in, dx_in_t, side_stream=Non
     else:
         LIB.call("sc_block_bwd_async", ctypes.byref(desc), ptr(dx_out), ptr(dx_out_t), ptr(dx_in), ptr(dx_in_t), stream_ptr(),
                  ctypes.c_void_p(side_stream.cuda_stream))
+
+
+# ------------------------------------------------------------------------------------------------ ModifiedResNet pieces (csrc/conv.hip)
+def im2col3x3(x, batch, h, w, c, stride, kpad, out_dtype, nchw_images=False):
+    """NHWC activation [B*H*W, C] (or the fp32 image tensor [B,C,H,W] when nchw_images) -> [B*Ho*Wo, kpad] patch matrix."""
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty(batch * ho * wo, kpad, dtype=out_dtype, device=x.device)
+    LIB.call("sc_im2col3x3", ptr(x), int(nchw_images), sc_dtype(out_dtype), batch, h, w, c, stride, kpad, ptr(out), stream_ptr())
+    return out
+
+
+def col2im3x3(dcols, batch, h, w, c, stride, kpad):
+    dx = torch.empty(batch * h * w, c, dtype=dcols.dtype, device=dcols.device)
+    LIB.call("sc_col2im3x3", ptr(dcols), sc_dtype(dcols.dtype), batch, h, w, c, stride, kpad, ptr(dx), stream_ptr())
+    return dx
+
+
+def avgpool_fwd(x, batch, h, w, c, k):
+    y = torch.empty(batch * (h // k) * (w // k), c, dtype=x.dtype, device=x.device)
+    LIB.call("sc_avgpool_fwd", ptr(x), sc_dtype(x.dtype), batch, h, w, c, k, ptr(y), stream_ptr())
+    return y
+
+
+def avgpool_bwd(dy, batch, h, w, c, k):
+    dx = torch.empty(batch * h * w, c, dtype=dy.dtype, device=dy.device)
+    LIB.call("sc_avgpool_bwd", ptr(dy), sc_dtype(dy.dtype), batch, h, w, c, k, ptr(dx), stream_ptr())
+    return dx
+
+
+def _bn_ws(rows, c, device):
+    return _workspace(LIB.raw("sc_bn_workspace_bytes")(rows, c), device, "bn")
+
+
+def bn_stats(x):
+    """x [rows, C] -> this rank's statistics triple [3C] (shifted sums + shift)."""
+    rows, c = x.shape
+    stats = torch.empty(3 * c, dtype=torch.float32, device=x.device)
+    ws = _bn_ws(rows, c, x.device)
+    LIB.call("sc_bn_stats", ptr(x), sc_dtype(x.dtype), rows, c, ptr(stats), ptr(ws), ws.numel(), stream_ptr())
+    return stats
+
+
+def bn_finish(stats, nparts, c, rows_per_part, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    mean = torch.empty(c, dtype=torch.float32, device=stats.device)
+    rstd = torch.empty_like(mean)
+    LIB.call("sc_bn_finish", ptr(stats), nparts, c, rows_per_part, float(eps), float(momentum), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+             stream_ptr())
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, relu, res=None):
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    LIB.call("sc_bn_apply", ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), int(relu), ptr(y), stream_ptr())
+    return y
+
+
+def bn_bwd_stats(dy, y, x, mean, rstd, relu):
+    rows, c = x.shape
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = _bn_ws(rows, c, x.device)
+    LIB.call("sc_bn_bwd_stats", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), int(relu), ptr(sums), ptr(ws), ws.numel(),
+             stream_ptr())
+    return sums
+
+
+def bn_bwd_apply(dy, y, x, mean, rstd, gamma, sums, total_rows, relu, dgamma, dbeta, accumulate, want_dres=False):
+    rows, c = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    LIB.call("sc_bn_bwd_apply", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), int(total_rows), int(relu),
+             int(accumulate), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
+    return dx, dres
+
+
+def attnpool_tokens_fwd(x, pos, batch, hw):
+    c = x.shape[1]
+    t = torch.empty(batch * (hw + 1), c, dtype=x.dtype, device=x.device)
+    LIB.call("sc_attnpool_tokens_fwd", ptr(x), sc_dtype(x.dtype), ptr(pos), batch, hw, c, ptr(t), stream_ptr())
+    return t
+
+
+def attnpool_tokens_bwd(dt, batch, hw):
+    c = dt.shape[1]
+    dx = torch.empty(batch * hw, c, dtype=dt.dtype, device=dt.device)
+    LIB.call("sc_attnpool_tokens_bwd", ptr(dt), sc_dtype(dt.dtype), batch, hw, c, ptr(dx), stream_ptr())
+    return dx

@@ -1,5 +1,5 @@
 """GPU, 2 ranks on one device over gloo (RCCL refuses duplicate devices, the collective call sites are the same):
-a data-parallel training step (rank-major shards -> embedding all-gather -> replicated global loss -> local gradient rows ->
+a data-parallel training step (rank-major shards -> embedding all-gather -> global loss head (by rows, or whole) -> local gradient rows ->
 bucketed SUM all-reduce -> AdamW) must reproduce the single-process step on the concatenated batch."""
 import os
 import socket
@@ -9,6 +9,9 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+
+
+_PROBE = {"tiny": "visual.proj", "test-small": "visual.proj", "test-rn": "visual.layer2.0.conv2.weight"}
 
 
 def _free_port():
@@ -49,14 +52,15 @@ def _run(rank, world, port, out, model_name="tiny", batch=8):
     for images, tokens in _batches(3, model_name, batch):
         a, b = D.shard_bounds(batch, rank, world)
         losses.append(tr.step(images[a:b].cuda(), tokens[a:b].cuda()).item())
-    out[rank] = (losses, model.param("visual.proj").cpu(), model.param("token_embedding.weight").cpu())
+    out[rank] = (losses, model.param(_PROBE[model_name]).cpu(), model.param("token_embedding.weight").cpu())
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_name,batch", [("tiny", 8), ("test-small", 128)])
+@pytest.mark.parametrize("model_name,batch", [("tiny", 8), ("test-small", 128), ("test-rn", 8)])
 def test_dp2_step_equals_dp1_step(model_name, batch):
     """("test-small", 128): 64 pairs per rank and a 128-wide embedding - the shapes the SHARDED loss head takes (each rank its rows x
-    all columns, statistics exchanged through dist.exchange_packets); ("tiny", 8) runs the replicated loss head."""
+    all columns, statistics exchanged through dist.exchange_packets); ("tiny", 8) runs the replicated loss head; ("test-rn", 8): the
+    ModifiedResNet tower, whose BatchNorm statistics and gradient sums are exchanged so that two ranks reproduce the whole-batch statistics."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from sparsify_clip_amd.model import ClipModel
@@ -71,7 +75,7 @@ def test_dp2_step_equals_dp1_step(model_name, batch):
         losses, proj, emb = out[rank]
         for got, w in zip(losses, want):
             assert abs(got - w) <= 2e-5 * abs(w), (rank, losses, want)
-        assert torch.allclose(proj, ref_model.param("visual.proj").cpu(), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(proj, ref_model.param(_PROBE[model_name]).cpu(), rtol=1e-4, atol=1e-6)
         assert torch.allclose(emb, ref_model.param("token_embedding.weight").cpu(), rtol=1e-4, atol=1e-6)
     assert out[0][0] == out[1][0]      # both ranks evaluate the identical global-batch loss
 

@@ -39,8 +39,9 @@ def test_dispatch_table_covers_every_reference_yaml():
         if raw is None:
             continue
         assert raw["model"] == "RN50"
-        with pytest.raises(ScError, match="--model ViT-B-32"):     # RN50 is rejected at load time, naming the override
-            finalize_config(raw, 3)
+        assert finalize_config(raw, 3)["model"] == "RN50"          # the YAMLs run as they are: ModifiedResNet is implemented (resnet.py)
+        with pytest.raises(ScError, match="not implemented natively"):
+            finalize_config(raw, 3, {"model": "RN101"})
         cfg = finalize_config(raw, 3, {"model": "ViT-B-32"})
         assert cfg["device_id"] == 3 and isinstance(cfg["learning_rate"], float) and cfg["learning_rate"] == 1e-4
         assert cfg["precision"] == "bf16" and cfg["model"] == "ViT-B-32" and cfg["batch_size"] == 256
@@ -138,7 +139,7 @@ def test_product_path_fails_loudly_without_gpu():
     with pytest.raises(ScError):
         ClipModel("tiny", device="cpu")
     with pytest.raises(ScError):
-        ClipModel("RN50", device="cuda:0")
+        ClipModel("RN101", device="cuda:0")
     import sparsify_clip_amd
     src = "".join(open(os.path.join(ROOT, "sparsify_clip_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "sparsify_clip_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src       # the product never routes through the oracle
@@ -164,17 +165,25 @@ def test_model_layout_without_gpu():
     """Parameter inventory of the native model == the oracle's open_clip-named state_dict (names, shapes, counts)."""
     from oracle.clip_model import create_model
     from sparsify_clip_amd import model as M
-    for name, total in [("ViT-B-32", 151_277_313), ("tiny", None)]:
+    from sparsify_clip_amd.resnet import ResNetVisual
+    for name, total in [("ViT-B-32", 151_277_313), ("tiny", None), ("RN50", 102_007_137), ("test-rn", None)]:
         ref = create_model(name)
         stub = M.ClipModel.__new__(M.ClipModel)
         stub.cfg = M.CONFIGS[name]
-        stub.grid = stub.cfg["image_size"] // stub.cfg["patch"]
-        stub.k_patch = 3 * stub.cfg["patch"] ** 2
+        stub.rn = None
+        if stub.cfg.get("v_kind") == "resnet":     # ModifiedResNet: parameters in the flat buffer, BatchNorm statistics as buffers
+            stub.rn = ResNetVisual(stub, stub.cfg)
+        else:
+            stub.grid = stub.cfg["image_size"] // stub.cfg["patch"]
+            stub.k_patch = 3 * stub.cfg["patch"] ** 2
         stub._layout()
         ref_shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
-        assert {k: tuple(s) for k, (o, s) in stub.slots.items()} == ref_shapes
+        mine = {k: tuple(s) for k, (o, s) in stub.slots.items()}
+        if stub.rn is not None:
+            mine.update({k: tuple(shape) for k, shape, _, _ in stub.rn.buffer_specs()})
+        assert mine == ref_shapes
         if total:
-            assert sum(int(np.prod(s)) for s in ref_shapes.values()) == total
+            assert sum(p.numel() for p in ref.parameters()) == total
         # buckets tile the trainable range without gaps or overlap, in backward order
         spans = [s for _, s in stub.buckets]
         assert spans[0][0] == 0 and spans[-1][1] == stub.n_trainable
