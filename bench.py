@@ -314,7 +314,7 @@ def main():
         tdist.barrier()
         tdist.destroy_process_group()
     if rank == 0:
-        if args.precision == "bf16":
+        if args.precision == "bf16" and trainer.model.rn is None:      # the replay set is the ViT towers' (the headline configuration)
             progress("roofline: replaying the step's NT GEMM launches under HIP events")
             out["roofline"] = gemm_roofline(trainer.model, device)
         if args.cpu_baseline and world == 1:

@@ -132,8 +132,8 @@ def test_runner_end_to_end(gpu, tmp_path, monkeypatch):
 
     monkeypatch.setattr(T, "step_loss", spy)
     from sparsify_clip_amd._lib import ScError
-    with pytest.raises(ScError, match="--model"):
-        sparsify_clip.run(["--config", str(path), "--device", "0"])                 # the YAML's literal RN50
+    with pytest.raises(ScError, match="not implemented natively"):
+        sparsify_clip.run(["--config", str(path), "--device", "0", "--model", "RN101"])
     out = sparsify_clip.run(["--config", str(path), "--device", "0", "--model", "tiny", "--steps-per-epoch", "3", "--precision", "fp32"])
     assert set(out) == {"runner_test"} and np.isfinite(out["runner_test"]["final"]["gap"])
     assert [c[0] for c in calls] == [0, 0, 0, 1, 1, 1] and [c[1] for c in calls] == [1, 2, 3, 4, 5, 6]
@@ -155,6 +155,15 @@ def test_runner_end_to_end(gpu, tmp_path, monkeypatch):
     m.load_state_dict(torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True))
     sd = torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True)
     assert torch.equal(m.param("visual.proj").cpu(), sd["module.visual.proj"])
+    # the same runner on the ModifiedResNet geometry (what the YAML's literal "RN50" selects at real size): the evaluation runs on the
+    # BatchNorm running statistics and the checkpoint carries them under open_clip's keys
+    out = sparsify_clip.run(["--config", str(path), "--device", "0", "--model", "test-rn", "--steps-per-epoch", "2", "--precision", "fp32", "--epochs", "1"])
+    assert np.isfinite(out["runner_test"]["final"]["gap"])
+    sd = torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True)
+    assert "module.visual.layer1.0.downsample.1.running_var" in sd and int(sd["module.visual.bn1.num_batches_tracked"]) == 2
+    m = ClipModel("test-rn", device=DEV, precision="fp32", seed=1)
+    m.load_state_dict(sd)
+    assert torch.equal(m.buffers["visual.bn1.running_mean"].cpu(), sd["module.visual.bn1.running_mean"])
 
 
 def test_full_state_sidecar_resume_is_bit_exact(gpu, tmp_path, monkeypatch):

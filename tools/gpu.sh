@@ -13,7 +13,8 @@
 #   pmc_loss     FETCH_SIZE / WRITE_SIZE + kernel times of the loss head at B = 8192 -> gpurun_out/pmc/loss_counters.txt
 #   loss         tools/loss_bench.py                       -> gpurun_out/loss_head_times.txt
 #   attn / pmc_attn   tools/attn_bench.py timings / SQ counters of the attention kernels -> gpurun_out/attention_times.txt, pmc/attn_counters.txt
-#   configs      bench.py for BASELINE configs C2 / C3 / C5 (per-GPU shards) and --precision fp32 -> gpurun_out/bench_c2|c3|c5|fp32.json
+#   configs      bench.py for BASELINE configs C2 / C3 / C5 (per-GPU shards), --precision fp32 and the YAMLs' own RN50 at batch 256
+#                                                         -> gpurun_out/bench_c2|c3|c5|fp32|rn50.json
 #   corun        tools/corun_bench.py: the persistent NT GEMM with 16 / 32 / 64 CUs taken by another stream, fixed lists vs tile tickets
 #                                                         -> gpurun_out/gemm_corun.txt
 #   ln           tools/ln_bench.py stand-alone LayerNorm forward / backward rates -> gpurun_out/layernorm_times.txt
@@ -76,7 +77,8 @@ for task in "$@"; do
       python3 tools/pmc_table.py attn $R/gpurun_out/pmc/a_sq1 $R/gpurun_out/pmc/a_sq2 > $R/gpurun_out/pmc/attn_counters.txt; cat $R/gpurun_out/pmc/attn_counters.txt ;;
     configs)   # one-GPU shard lines of the other BASELINE configurations and the fp32 parity path
       for spec in "c2 --experiment experiment_2 --local-batch 512" "c3 --experiment experiment_4 --local-batch 512" \
-                  "c5 --experiment experiment_10 --model ViT-L-14 --local-batch 512" "fp32 --precision fp32 --local-batch 256"; do
+                  "c5 --experiment experiment_10 --model ViT-L-14 --local-batch 512" "fp32 --precision fp32 --local-batch 256" \
+                  "rn50 --model RN50 --local-batch 256"; do
         set -- $spec; name=$1; shift
         timeout -k 10 500 python bench.py --steps 4 --warmup 2 --cpu-baseline 0 --simulate-dp 1 "$@" > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; rc=$?
         echo "$name rc=$rc"; cut -c1-330 gpurun_out/bench_$name.json; echo; [ $rc = 0 ] || exit $rc
