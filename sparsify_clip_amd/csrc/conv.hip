@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int BN_MAX_BLOCKS = 512;
+constexpr int BN_MAX_BLOCKS = 256;
 
 // ---------------------------------------------------------------- 3x3 convolution lowering (padding 1, stride 1 or 2)
 // out[(b, yo, xo)][tap * C + c] = x[b][yo*stride + ky - 1][xo*stride + kx - 1][c]  (tap = 3 ky + kx; 0 outside; columns >= 9C are 0)
@@ -230,6 +230,196 @@ __global__ __launch_bounds__(256) void attnpool_tokens_bwd_kernel(const T* dt, i
     }
 }
 
+
+// ================================================================ 4-channel-per-thread forms (C % 4 == 0): 8- / 16-byte accesses
+// The scalar kernels above are the general forms (any C; the 3-channel image input); the step runs these.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_v4_kernel(const T* x, int B, int H, int W, int C, int stride, int Ho, int Wo, int kpad, T* out) {
+    const int k4 = kpad >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * k4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % k4) * 4;
+        const int64_t row = i / k4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col < 9 * C) {
+            const int tap = col / C, c = col - tap * C;
+            const int xo = (int)(row % Wo), yo = (int)((row / Wo) % Ho), b = (int)(row / ((int64_t)Wo * Ho));
+            const int y = yo * stride + tap / 3 - 1, xx = xo * stride + tap % 3 - 1;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) v = io<T>::ld4(x + (((int64_t)b * H + y) * W + xx) * C + c);
+        }
+        io<T>::st4(out + row * kpad + col, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_v4_kernel(const T* dcols, int B, int H, int W, int C, int stride, int Ho, int Wo, int kpad, T* dx) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t p = i / c4n;
+        const int xx = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = y + 1 - ky;
+            if (ty < 0 || ty % stride != 0 || ty / stride >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = xx + 1 - kx;
+                if (tx < 0 || tx % stride != 0 || tx / stride >= Wo) continue;
+                s += io<T>::ld4(dcols + (((int64_t)b * Ho + ty / stride) * Wo + tx / stride) * kpad + (3 * ky + kx) * C + c);
+            }
+        }
+        io<T>::st4(dx + p * C + c, s);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_v4_kernel(const T* x, int B, int H, int W, int C, int k, T* y) {
+    const int Ho = H / k, Wo = W / k, c4n = C >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * c4n;
+    const float inv = 1.0f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t p = i / c4n;
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) s += io<T>::ld4(x + (((int64_t)b * H + yo * k + dy) * W + xo * k + dx) * C + c);
+        io<T>::st4(y + p * C + c, s * inv);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_v4_kernel(const T* dy, int B, int H, int W, int C, int k, T* dx) {
+    const int Ho = H / k, Wo = W / k, c4n = C >> 2;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    const float inv = 1.0f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t p = i / c4n;
+        const int xx = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y / k < Ho && xx / k < Wo) v = io<T>::ld4(dy + (((int64_t)b * Ho + y / k) * Wo + xx / k) * C + c) * inv;
+        io<T>::st4(dx + p * C + c, v);
+    }
+}
+
+// Column reductions over x [R, C]: the 256 threads of a block form RPI = 256 / LPR row lanes of LPR = chunk / 4 four-channel lanes
+// (chunk = min(C, 1024) channels per blockIdx.x); every thread accumulates its four channels over every RPI-th row of the block's
+// row slab, the row lanes are then summed through LDS in lane order.  kind 0: sum (x - k), sum (x - k)^2 with k = x[0][c];
+// kind 1 (backward): sum g, sum g * xhat with g = dy masked by y > 0.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T* dy, const T* y, const float* mean, const float* rstd, int64_t R, int C,
+                                                            int lpr, int64_t rows_per_block, int relu, float* partial) {
+    __shared__ f32x4 sm[2][256];
+    const int t = threadIdx.x, lc = t % lpr, lr = t / lpr, rpi = 256 / lpr;
+    const int c = blockIdx.x * (lpr * 4) + lc * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    f32x4 k = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    if (KIND == 0) k = io<T>::ld4(x + c);
+    else { k = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
+    for (int64_t r = r0 + lr; r < r1; r += rpi) {
+        const f32x4 xv = io<T>::ld4(x + r * C + c);
+        if (KIND == 0) {
+            const f32x4 d = xv - k;
+            a += d;
+            b += d * d;
+        } else {
+            f32x4 g = io<T>::ld4(dy + r * C + c);
+            if (relu) {
+                const f32x4 yv = io<T>::ld4(y + r * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+            }
+            a += g;
+            b += g * ((xv - k) * rs);
+        }
+    }
+    sm[0][t] = a; sm[1][t] = b;
+    __syncthreads();
+    if (lr == 0) {
+        for (int j = 1; j < rpi; ++j) { a += sm[0][j * lpr + lc]; b += sm[1][j * lpr + lc]; }
+        *(f32x4*)(partial + ((int64_t)blockIdx.y * 2 + 0) * C + c) = a;
+        *(f32x4*)(partial + ((int64_t)blockIdx.y * 2 + 1) * C + c) = b;
+    }
+}
+// out[0..C) = sum_b partial[b][0], out[C..2C) = sum_b partial[b][1] (fixed order: four slices of the blocks per channel, then the slices);
+// shift != null: out[2C..3C) = shift values x[0][c] (forward statistics)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_collect_v_kernel(const float* partial, int nblocks, int C, const T* shift_row, float* out) {
+    __shared__ float sm[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int k = sl; k < nblocks; k += 4) {
+            a += partial[((int64_t)k * 2 + 0) * C + c];
+            b += partial[((int64_t)k * 2 + 1) * C + c];
+        }
+    sm[0][sl][cl] = a; sm[1][sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        out[c] = ((sm[0][0][cl] + sm[0][1][cl]) + sm[0][2][cl]) + sm[0][3][cl];
+        out[C + c] = ((sm[1][0][cl] + sm[1][1][cl]) + sm[1][2][cl]) + sm[1][3][cl];
+        if (shift_row) out[2 * C + c] = io<T>::ld(shift_row + c);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                          const T* res, int64_t n4, int C, int relu, T* y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+        f32x4 v = (io<T>::ld4(x + i * 4) - mu) * rs * g + bt;
+        if (res) v += io<T>::ld4(res + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        io<T>::st4(y + i * 4, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const T* y, const T* x, const float* mean, const float* rstd, const float* gamma,
+                                                              const float* sums, float count, int64_t n4, int C, int relu, int accumulate, T* dx, T* dres,
+                                                              float* dgamma, float* dbeta) {
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sums[C + c];
+            dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sums[c];
+        }
+    const float inv = 1.0f / count;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        f32x4 g = io<T>::ld4(dy + i * 4);
+        if (relu) {
+            const f32x4 yv = io<T>::ld4(y + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+        }
+        const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), gm = *(const f32x4*)(gamma + c);
+        const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
+        const f32x4 xh = (io<T>::ld4(x + i * 4) - mu) * rs;
+        io<T>::st4(dx + i * 4, gm * rs * (g - sg * inv - xh * sgx * inv));
+        if (dres) io<T>::st4(dres + i * 4, g);
+    }
+}
+
+// four-channel lanes per row for the column reductions, or 0 when the channel count does not fit the vector form
+int bn_lpr(int64_t c) {
+    if (c % 4 != 0) return 0;
+    const int64_t chunk = c <= 1024 ? c : 1024;
+    if (c % chunk != 0) return 0;
+    const int lpr = (int)(chunk / 4);
+    return (lpr & (lpr - 1)) == 0 ? lpr : 0;
+}
+
+// SC_CONV_SCALAR=<bit mask>: force the general (scalar) kernels - 1 im2col, 2 col2im, 4 average pools, 8 BatchNorm statistics, 16 BatchNorm
+// apply, 32 BatchNorm backward sums, 64 BatchNorm backward apply (A/B and bisection knob)
+bool vec_ok(int bit) {
+    static const int mask = [] { const char* e = getenv("SC_CONV_SCALAR"); return e ? atoi(e) : 0; }();
+    return !(mask & bit);
+}
 unsigned stream_grid(int64_t total) { return (unsigned)min((int64_t)4096, max((int64_t)1, sc_cdiv(total, 256))); }
 int bn_blocks(int64_t rows) { return (int)min((int64_t)BN_MAX_BLOCKS, max((int64_t)1, sc_cdiv(rows, 64))); }
 
@@ -249,8 +439,11 @@ extern "C" int sc_im2col3x3(const void* x, int in_nchw_f32, int dtype, int64_t b
     const int64_t total = batch * Ho * Wo * kpad;
     hipStream_t st = (hipStream_t)stream;
 #define IM(TI, TO, N) hipLaunchKernelGGL((im2col3x3_kernel<TI, TO, N>), dim3(stream_grid(total)), dim3(256), 0, st, (const TI*)x, (int)batch, (int)h, (int)w, (int)c, (int)stride, Ho, Wo, (int)kpad, (TO*)out)
+#define IMV(T) hipLaunchKernelGGL(im2col3x3_v4_kernel<T>, dim3(stream_grid(total / 4)), dim3(256), 0, st, (const T*)x, (int)batch, (int)h, (int)w, (int)c, (int)stride, Ho, Wo, (int)kpad, (T*)out)
     if (in_nchw_f32) SC_DT(dtype, IM(float, bf16_t, true), IM(float, float, true));
+    else if (c % 4 == 0 && kpad % 4 == 0 && vec_ok(1)) SC_DT(dtype, IMV(bf16_t), IMV(float));
     else SC_DT(dtype, IM(bf16_t, bf16_t, false), IM(float, float, false));
+#undef IMV
 #undef IM
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -262,7 +455,10 @@ extern "C" int sc_col2im3x3(const void* dcols, int dtype, int64_t batch, int64_t
     const int64_t total = batch * h * w * c;
     hipStream_t st = (hipStream_t)stream;
 #define CI(T) hipLaunchKernelGGL(col2im3x3_kernel<T>, dim3(stream_grid(total)), dim3(256), 0, st, (const T*)dcols, (int)batch, (int)h, (int)w, (int)c, (int)stride, Ho, Wo, (int)kpad, (T*)dx)
-    SC_DT(dtype, CI(bf16_t), CI(float));
+#define CIV(T) hipLaunchKernelGGL(col2im3x3_v4_kernel<T>, dim3(stream_grid(total / 4)), dim3(256), 0, st, (const T*)dcols, (int)batch, (int)h, (int)w, (int)c, (int)stride, Ho, Wo, (int)kpad, (T*)dx)
+    if (c % 4 == 0 && kpad % 4 == 0 && vec_ok(2)) SC_DT(dtype, CIV(bf16_t), CIV(float));
+    else SC_DT(dtype, CI(bf16_t), CI(float));
+#undef CIV
 #undef CI
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -272,7 +468,10 @@ extern "C" int sc_avgpool_fwd(const void* x, int dtype, int64_t batch, int64_t h
     const int64_t total = batch * (h / k) * (w / k) * c;
     hipStream_t st = (hipStream_t)stream;
 #define AP(T) hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(stream_grid(total)), dim3(256), 0, st, (const T*)x, (int)batch, (int)h, (int)w, (int)c, (int)k, (T*)y)
-    SC_DT(dtype, AP(bf16_t), AP(float));
+#define APV(T) hipLaunchKernelGGL(avgpool_fwd_v4_kernel<T>, dim3(stream_grid(total / 4)), dim3(256), 0, st, (const T*)x, (int)batch, (int)h, (int)w, (int)c, (int)k, (T*)y)
+    if (c % 4 == 0 && vec_ok(4)) SC_DT(dtype, APV(bf16_t), APV(float));
+    else SC_DT(dtype, AP(bf16_t), AP(float));
+#undef APV
 #undef AP
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -282,7 +481,10 @@ extern "C" int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t 
     const int64_t total = batch * h * w * c;
     hipStream_t st = (hipStream_t)stream;
 #define AP(T) hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(stream_grid(total)), dim3(256), 0, st, (const T*)dy, (int)batch, (int)h, (int)w, (int)c, (int)k, (T*)dx)
-    SC_DT(dtype, AP(bf16_t), AP(float));
+#define APV(T) hipLaunchKernelGGL(avgpool_bwd_v4_kernel<T>, dim3(stream_grid(total / 4)), dim3(256), 0, st, (const T*)dy, (int)batch, (int)h, (int)w, (int)c, (int)k, (T*)dx)
+    if (c % 4 == 0 && vec_ok(4)) SC_DT(dtype, APV(bf16_t), APV(float));
+    else SC_DT(dtype, AP(bf16_t), AP(float));
+#undef APV
 #undef AP
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -303,7 +505,16 @@ extern "C" int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, fl
         hipLaunchKernelGGL(bn_partial_kernel<T>, grid, dim3(256), 0, st, (const T*)x, rows, (int)c, rpb, (float*)ws);                      \
         hipLaunchKernelGGL(bn_collect_kernel<T>, dim3((unsigned)sc_cdiv(c, 256)), dim3(256), 0, st, (const T*)x, (const float*)ws, nbe, (int)c, stats); \
     } while (0)
-    SC_DT(dtype, BS(bf16_t), BS(float));
+#define BSV(T)                                                                                                                             \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL((bn_partial_v4_kernel<T, 0>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)nullptr, \
+                           (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, (int)c, lpr, rpb, 0, (float*)ws);        \
+        hipLaunchKernelGGL(bn_collect_v_kernel<T>, dim3((unsigned)sc_cdiv(c, 64)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const T*)x, stats); \
+    } while (0)
+    const int lpr = vec_ok(8) ? bn_lpr(c) : 0;
+    if (lpr) SC_DT(dtype, BSV(bf16_t), BSV(float));
+    else SC_DT(dtype, BS(bf16_t), BS(float));
+#undef BSV
 #undef BS
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -323,7 +534,10 @@ extern "C" int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, co
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n, (int)c, relu, (T*)y)
-    SC_DT(dtype, BA(bf16_t), BA(float));
+#define BAV(T) hipLaunchKernelGGL(bn_apply_v4_kernel<T>, dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n / 4, (int)c, relu, (T*)y)
+    if (c % 4 == 0 && vec_ok(16)) SC_DT(dtype, BAV(bf16_t), BAV(float));
+    else SC_DT(dtype, BA(bf16_t), BA(float));
+#undef BAV
 #undef BA
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -338,9 +552,17 @@ extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)sc_cdiv(c, 256), (unsigned)nbe);
 #define BB(T) hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, rows, (int)c, rpb, relu, (float*)ws)
-    SC_DT(dtype, BB(bf16_t), BB(float));
+#define BBV(T) hipLaunchKernelGGL((bn_partial_v4_kernel<T, 1>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, rows, (int)c, lpr, rpb, relu, (float*)ws)
+    const int lpr = vec_ok(32) ? bn_lpr(c) : 0;
+    if (lpr) {
+        SC_DT(dtype, BBV(bf16_t), BBV(float));
+        hipLaunchKernelGGL(bn_collect_v_kernel<float>, dim3((unsigned)sc_cdiv(c, 64)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const float*)nullptr, sums);
+    } else {
+        SC_DT(dtype, BB(bf16_t), BB(float));
+        hipLaunchKernelGGL(bn_bwd_collect_kernel, dim3((unsigned)sc_cdiv(c, 256)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, sums);
+    }
+#undef BBV
 #undef BB
-    hipLaunchKernelGGL(bn_bwd_collect_kernel, dim3((unsigned)sc_cdiv(c, 256)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, sums);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
@@ -352,7 +574,10 @@ extern "C" int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, (float)total_rows, n, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
-    SC_DT(dtype, BA(bf16_t), BA(float));
+#define BAV(T) hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<T>, dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
+    if (c % 4 == 0 && vec_ok(64)) SC_DT(dtype, BAV(bf16_t), BAV(float));
+    else SC_DT(dtype, BA(bf16_t), BA(float));
+#undef BAV
 #undef BA
     SC_CHECK_LAUNCH();
     return SC_OK;

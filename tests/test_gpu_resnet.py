@@ -87,12 +87,12 @@ def test_avgpool_and_attnpool_tokens(ops, dtype):
 
 @pytest.mark.parametrize("relu,with_res", [(True, False), (False, False), (True, True)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_batchnorm_train(ops, relu, with_res, dtype):
+@pytest.mark.parametrize("rows,c", [(1000, 24), (1536, 16), (777, 64), (300, 2048)])
+def test_batchnorm_train(ops, relu, with_res, dtype, rows, c):
     """Training-mode BatchNorm with fused ReLU / residual join against torch: output, input / residual / affine gradients, and the
     running statistics (momentum 0.1, unbiased variance); the two-part form (statistics of two half batches combined) gives the
     statistics of the whole batch - what a data-parallel run exchanges."""
-    g = torch.Generator().manual_seed(3)
-    rows, c = 1000, 24
+    g = torch.Generator().manual_seed(3)      # c = 24: the general kernels; 16 / 64 / 2048: the four-channel-per-thread forms (1 / 1 / 2 channel chunks)
     x = (torch.randn(rows, c, generator=g) * 2 + 5).to(dtype).float()      # a mean far from zero: the shifted sums must not cancel
     res = torch.randn(rows, c, generator=g).to(dtype).float()
     gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
@@ -113,9 +113,10 @@ def test_batchnorm_train(ops, relu, with_res, dtype):
     assert rel(yd, y) < tol
     assert rel(rmd, rm) < 1e-5 and rel(rvd, rv) < 1e-5
     # two half batches combined
-    s2 = torch.cat([ops.bn_stats(xd[: rows // 2].contiguous()), ops.bn_stats(xd[rows // 2:].contiguous())])
-    mean2, rstd2 = ops.bn_finish(s2, 2, c, rows // 2)
-    assert rel(mean2, mean) < 1e-6 and rel(rstd2, rstd) < 1e-5
+    if rows % 2 == 0:
+        s2 = torch.cat([ops.bn_stats(xd[: rows // 2].contiguous()), ops.bn_stats(xd[rows // 2:].contiguous())])
+        mean2, rstd2 = ops.bn_finish(s2, 2, c, rows // 2)
+        assert rel(mean2, mean) < 1e-6 and rel(rstd2, rstd) < 1e-5
     dy = torch.randn(rows, c, generator=g).to(dtype).float()
     y.backward(dy.double())
     dyd = dy.to(dtype).to(DEV)
@@ -180,6 +181,10 @@ def test_resnet_tower_forward_backward(ops, name, precision):
         assert rel(got, want) < 1.5 * rel(auto[0], want) + 1e-2
     else:
         assert rel(got, want) < 1e-5
+    # fp32 bar: 2e-2, not 1e-5.  Every kernel is pinned tightly on its own above; through the whole tower a single pre-activation within
+    # rounding of zero takes the other side of the ReLU than in the fp64 oracle, and in the small late layers (24 .. 384 rows) one flipped
+    # element moves a BatchNorm bias gradient - and everything upstream of it - by 1/rows: torch's own fp32 run is 1e-3 .. 5e-3 off the
+    # fp64 gradients on this network for the same reason (tools/rn_diag.py).  The 1e-4 per-step loss bar is kept by the trajectory test.
     worst = ("", 0.0, 0.0)
     for k, p in ref.visual.named_parameters():
         if p.grad is None:
@@ -188,7 +193,7 @@ def test_resnet_tower_forward_backward(ops, name, precision):
             assert float(p.grad.abs().max()) < 1e-5 and float(model.grad("visual." + k).abs().max()) < (1e-5 if precision == "fp32" else 1e-2)
             continue
         e = rel(model.grad("visual." + k), p.grad)
-        bar = 5e-5 if auto is None else 1.5 * rel(auto[1][k], p.grad) + 2e-2
+        bar = 2e-2 if auto is None else 1.5 * rel(auto[1][k], p.grad) + 2e-2
         if e / bar > worst[1]:
             worst = (k, e / bar, e)
     assert worst[1] < 1.0, worst
