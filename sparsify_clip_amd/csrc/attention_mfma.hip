@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
 // alternate query tiles in pass 1 / alternate key tiles in pass 2, so a CU holds two waves per SIMD instead of one with the same
 // LDS footprint - the one-wave form spent 72 % of its wave cycles in s_waitcnt (profiles/r02_attention_pmc_counters.txt) with
 // nothing to switch to.  Workgroup barriers: after staging, between the passes (row statistics), before the column-sum hand-over.
-template <int NT, bool CAUSAL, int WPH>
-__global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
+template <int NT, bool CAUSAL, int WPH, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_mfma_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total_heads,
                                                             float scale, float* cs_part /* [batch][3 W] column sums of d_qkv per image, or null */) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_mfma_kernel(const bf16_t* qkv
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = wave / WPH, half = wave % WPH;     // head slot of the workgroup, which of the head's WPH waves
-    const int head_raw = blockIdx.x * (8 / WPH) + slot;
+    const int head_raw = blockIdx.x * (WAVES / WPH) + slot;
     const bool valid = head_raw < total_heads;           // a surplus slot repeats the last head's work and stores nothing (no early exit: barriers)
     const int head = valid ? head_raw : total_heads - 1;
     bf16_t* Ks = lds_bwd + slot * HEAD_ELEMS;
@@ -344,23 +344,29 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total, b
 }
 
 // WPH = 2 (four heads per workgroup) measured 208 / 242 us at S = 77 / 50 against 250 / 276 us for WPH = 4 (profiles/r02_attention_times.txt)
-template <int NT, int WPH>
+// Heads per workgroup: with two heads (256 threads, 58 / 73 KiB of LDS at S <= 64 / 80) TWO workgroups share a CU, so one stages its
+// images while the other computes; four heads per workgroup (512 threads, 116 / 146 KiB) leave one workgroup per CU.  Same waves per
+// SIMD either way.  SC_ATTN_BWD_WAVES=8 selects the four-head form (A/B).
+template <int NT, int WPH, int WAVES>
 int launch_bwd_w(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
-    const size_t lds = (size_t)(8 / WPH) * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
-    const dim3 grid((unsigned)sc_cdiv(total, 8 / WPH));
+    constexpr int HPW = WAVES / WPH;
+    const size_t lds = (size_t)HPW * (3 * NT * 16 * LDR + 3 * NT * 16 * 2) * sizeof(bf16_t);
+    const dim3 grid((unsigned)sc_cdiv(total, HPW));
     if (causal) {
-        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true, WPH>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true, WPH>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
+        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, true, WPH, WAVES>, lds));
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, true, WPH, WAVES>), grid, dim3(WAVES * 64), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     } else {
-        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false, WPH>, lds));
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false, WPH>), grid, dim3(512), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
+        SC_TRY(reserve_lds(attn_bwd_mfma_kernel<NT, false, WPH, WAVES>, lds));
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT, false, WPH, WAVES>), grid, dim3(WAVES * 64), lds, st, qkv, d_out, d_qkv, S, W, H, total, 0.125f, cs_part);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
 template <int NT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
-    return launch_bwd_w<NT, 2>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
+    static const bool four_heads = [] { const char* e = getenv("SC_ATTN_BWD_WAVES"); return e && e[0] == '8'; }();
+    if (four_heads) return launch_bwd_w<NT, 2, 8>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
+    return launch_bwd_w<NT, 2, 4>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
 }
 
 }  // namespace
