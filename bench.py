@@ -130,13 +130,16 @@ def gemm_roofline(model, device):
     for (m, n, k), kind, reps in launches:
         a, b, out, epi, keep = gemm_launch_operands(m, n, k, kind, device)
         ops.gemm_bf16_nt(a, b, out=out, epi=epi)
+        # three samples of FOUR back-to-back launches each (the event pair then brackets kernel time, not the ~5 us between an event and the
+        # launch behind it - with one launch per pair the figure read 3-5 % above rocprofv3's kernel durations); the median sample counts
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         for s, e in evs:
             s.record()
-            ops.gemm_bf16_nt(a, b, out=out, epi=epi)
+            for _ in range(4):
+                ops.gemm_bf16_nt(a, b, out=out, epi=epi)
             e.record()
         torch.cuda.synchronize()
-        ms = sorted(s.elapsed_time(e) for s, e in evs)[1]
+        ms = sorted(s.elapsed_time(e) for s, e in evs)[1] / 4.0
         total_flops += 2.0 * m * n * k * reps
         total_ms += ms * reps
         count += reps
