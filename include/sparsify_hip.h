@@ -335,7 +335,9 @@ int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t h, int64_t 
  * (momentum, unbiased variance; NULL skips it).  sc_bn_apply: y = act((x-mean)*rstd*gamma + beta (+ res)), act = ReLU if relu.
  * Backward: sc_bn_bwd_stats gives sums[2c] = sum g | sum g*xhat over this rank's rows (g = dy masked by y > 0 if relu; SUM them over
  * ranks for a synchronised BatchNorm); sc_bn_bwd_apply writes dx, optionally dres = g (the gradient of the residual input),
- * and dgamma / dbeta (+= if accumulate) from `sums` with total_rows = rows of the whole batch. */
+ * and dgamma / dbeta (+= if accumulate) from `sums` with total_rows = rows of the whole batch.  y == NULL with relu (forward WITHOUT a
+ * residual, channel count a multiple of 4 that the vector kernels take): the ReLU mask is recomputed from x, gamma, beta - one tensor
+ * less to read in both backward passes. */
 size_t sc_bn_workspace_bytes(int64_t rows, int64_t c);
 int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, float* stats, void* ws, size_t ws_bytes, void* stream);
 int sc_bn_finish(const float* stats, int64_t nparts, int64_t c, int64_t rows_per_part, float eps, float momentum, float* mean, float* rstd,
@@ -343,10 +345,10 @@ int sc_bn_finish(const float* stats, int64_t nparts, int64_t c, int64_t rows_per
 int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd, const float* gamma, const float* beta,
                 const void* res, int relu, void* y, void* stream);
 int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
-                    int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
+                    const float* gamma, const float* beta, int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
 int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
-                    const float* gamma, const float* sums, int64_t total_rows, int relu, int accumulate, void* dx, void* dres, float* dgamma,
-                    float* dbeta, void* stream);
+                    const float* gamma, const float* beta, const float* sums, int64_t total_rows, int relu, int accumulate, void* dx, void* dres,
+                    float* dgamma, float* dbeta, void* stream);
 /* AttentionPool2d token assembly: tokens[b][0] = mean_p x[b][p] + pos[0], tokens[b][p+1] = x[b][p] + pos[p+1]; backward w.r.t. x */
 int sc_attnpool_tokens_fwd(const void* x, int dtype, const float* pos, int64_t batch, int64_t hw, int64_t c, void* tokens, void* stream);
 int sc_attnpool_tokens_bwd(const void* dtokens, int dtype, int64_t batch, int64_t hw, int64_t c, void* dx, void* stream);

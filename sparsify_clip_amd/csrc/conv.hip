@@ -308,16 +308,20 @@ __global__ __launch_bounds__(256) void avgpool_bwd_v4_kernel(const T* dy, int B,
 // row slab, the row lanes are then summed through LDS in lane order.  kind 0: sum (x - k), sum (x - k)^2 with k = x[0][c];
 // kind 1 (backward): sum g, sum g * xhat with g = dy masked by y > 0.
 template <typename T, int KIND>
-__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T* dy, const T* y, const float* mean, const float* rstd, int64_t R, int C,
-                                                            int lpr, int64_t rows_per_block, int relu, float* partial) {
+__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T* dy, const T* y, const float* mean, const float* rstd, const float* gamma,
+                                                            const float* beta, int64_t R, int C, int lpr, int64_t rows_per_block, int relu, float* partial) {
     __shared__ f32x4 sm[2][256];
     const int t = threadIdx.x, lc = t % lpr, lr = t / lpr, rpi = 256 / lpr;
     const int c = blockIdx.x * (lpr * 4) + lc * 4;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     f32x4 k = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
     if (KIND == 0) k = io<T>::ld4(x + c);
-    else { k = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
+    else {
+        k = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c);
+        if (relu && !y) { gm = *(const f32x4*)(gamma + c); bt = *(const f32x4*)(beta + c); }
+    }
     for (int64_t r = r0 + lr; r < r1; r += rpi) {
         const f32x4 xv = io<T>::ld4(x + r * C + c);
         if (KIND == 0) {
@@ -326,13 +330,14 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T*
             b += d * d;
         } else {
             f32x4 g = io<T>::ld4(dy + r * C + c);
-            if (relu) {
-                const f32x4 yv = io<T>::ld4(y + r * C + c);
+            const f32x4 xh = (xv - k) * rs;
+            if (relu) {   // the ReLU's mask: from the stored output, or (no residual in the forward) recomputed from x - one tensor less to read
+                const f32x4 yv = y ? io<T>::ld4(y + r * C + c) : xh * gm + bt;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
             }
             a += g;
-            b += g * ((xv - k) * rs);
+            b += g * xh;
         }
     }
     sm[0][t] = a; sm[1][t] = b;
@@ -381,8 +386,8 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* x, const floa
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const T* y, const T* x, const float* mean, const float* rstd, const float* gamma,
-                                                              const float* sums, float count, int64_t n4, int C, int relu, int accumulate, T* dx, T* dres,
-                                                              float* dgamma, float* dbeta) {
+                                                              const float* beta, const float* sums, float count, int64_t n4, int C, int relu, int accumulate,
+                                                              T* dx, T* dres, float* dgamma, float* dbeta) {
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += 256) {
             dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sums[C + c];
@@ -392,14 +397,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
         f32x4 g = io<T>::ld4(dy + i * 4);
-        if (relu) {
-            const f32x4 yv = io<T>::ld4(y + i * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
-        }
         const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), gm = *(const f32x4*)(gamma + c);
         const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
         const f32x4 xh = (io<T>::ld4(x + i * 4) - mu) * rs;
+        if (relu) {
+            const f32x4 yv = y ? io<T>::ld4(y + i * 4) : xh * gm + *(const f32x4*)(beta + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+        }
         io<T>::st4(dx + i * 4, gm * rs * (g - sg * inv - xh * sgx * inv));
         if (dres) io<T>::st4(dres + i * 4, g);
     }
@@ -508,7 +513,8 @@ extern "C" int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, fl
 #define BSV(T)                                                                                                                             \
     do {                                                                                                                                   \
         hipLaunchKernelGGL((bn_partial_v4_kernel<T, 0>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)nullptr, \
-                           (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, (int)c, lpr, rpb, 0, (float*)ws);        \
+                           (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, (int)c, lpr, \
+                           rpb, 0, (float*)ws);                                                                                            \
         hipLaunchKernelGGL(bn_collect_v_kernel<T>, dim3((unsigned)sc_cdiv(c, 64)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const T*)x, stats); \
     } while (0)
     const int lpr = vec_ok(8) ? bn_lpr(c) : 0;
@@ -543,8 +549,10 @@ extern "C" int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, co
     return SC_OK;
 }
 extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
-                               int relu, float* sums, void* ws, size_t ws_bytes, void* stream) {
-    SC_REQUIRE(dy && x && sums && ws && mean && rstd && rows > 0 && c > 0 && (!relu || y), SC_ERR_ARG, "sc_bn_bwd_stats: bad argument");
+                               const float* gamma, const float* beta, int relu, float* sums, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(dy && x && sums && ws && mean && rstd && rows > 0 && c > 0, SC_ERR_ARG, "sc_bn_bwd_stats: bad argument");
+    SC_REQUIRE(!relu || y || (gamma && beta && bn_lpr(c) && vec_ok(32)), SC_ERR_ARG,
+               "sc_bn_bwd_stats: ReLU needs the stored output y (or gamma and beta, for a channel count the four-channel kernels take)");
     SC_REQUIRE(ws_bytes >= sc_bn_workspace_bytes(rows, c), SC_ERR_WORKSPACE, "sc_bn_bwd_stats: workspace too small");
     const int nb = bn_blocks(rows);
     const int64_t rpb = sc_cdiv(rows, nb);
@@ -552,7 +560,7 @@ extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)sc_cdiv(c, 256), (unsigned)nbe);
 #define BB(T) hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, rows, (int)c, rpb, relu, (float*)ws)
-#define BBV(T) hipLaunchKernelGGL((bn_partial_v4_kernel<T, 1>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, rows, (int)c, lpr, rpb, relu, (float*)ws)
+#define BBV(T) hipLaunchKernelGGL((bn_partial_v4_kernel<T, 1>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, rows, (int)c, lpr, rpb, relu, (float*)ws)
     const int lpr = vec_ok(32) ? bn_lpr(c) : 0;
     if (lpr) {
         SC_DT(dtype, BBV(bf16_t), BBV(float));
@@ -567,14 +575,15 @@ extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int
     return SC_OK;
 }
 extern "C" int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
-                               const float* gamma, const float* sums, int64_t total_rows, int relu, int accumulate, void* dx, void* dres, float* dgamma,
-                               float* dbeta, void* stream) {
-    SC_REQUIRE(dy && x && dx && sums && mean && rstd && gamma && dgamma && dbeta && rows > 0 && c > 0 && total_rows >= rows && (!relu || y), SC_ERR_ARG,
+                               const float* gamma, const float* beta, const float* sums, int64_t total_rows, int relu, int accumulate, void* dx, void* dres,
+                               float* dgamma, float* dbeta, void* stream) {
+    SC_REQUIRE(dy && x && dx && sums && mean && rstd && gamma && dgamma && dbeta && rows > 0 && c > 0 && total_rows >= rows, SC_ERR_ARG,
                "sc_bn_bwd_apply: bad argument");
+    SC_REQUIRE(!relu || y || (beta && c % 4 == 0 && vec_ok(64)), SC_ERR_ARG, "sc_bn_bwd_apply: ReLU needs the stored output y (or beta, with c % 4 == 0)");
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, (float)total_rows, n, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
-#define BAV(T) hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<T>, dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
+#define BAV(T) hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<T>, dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, beta, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
     if (c % 4 == 0 && vec_ok(64)) SC_DT(dtype, BAV(bf16_t), BAV(float));
     else SC_DT(dtype, BA(bf16_t), BA(float));
 #undef BAV

@@ -498,21 +498,30 @@ def bn_apply(x, mean, rstd, gamma, beta, relu, res=None):
     return y
 
 
-def bn_bwd_stats(dy, y, x, mean, rstd, relu):
+def bn_mask_from_x(c) -> bool:
+    """Channel counts for which the BatchNorm backward can recompute the ReLU mask from x (y = None) instead of reading the stored output."""
+    if c % 4 or os.environ.get("SC_CONV_SCALAR", "0") != "0":
+        return False
+    chunk = c if c <= 1024 else 1024
+    lpr = chunk // 4
+    return c % chunk == 0 and lpr & (lpr - 1) == 0
+
+
+def bn_bwd_stats(dy, y, x, mean, rstd, relu, gamma=None, beta=None):
     rows, c = x.shape
     sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
     ws = _bn_ws(rows, c, x.device)
-    LIB.call("sc_bn_bwd_stats", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), int(relu), ptr(sums), ptr(ws), ws.numel(),
-             stream_ptr())
+    LIB.call("sc_bn_bwd_stats", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), int(relu), ptr(sums),
+             ptr(ws), ws.numel(), stream_ptr())
     return sums
 
 
-def bn_bwd_apply(dy, y, x, mean, rstd, gamma, sums, total_rows, relu, dgamma, dbeta, accumulate, want_dres=False):
+def bn_bwd_apply(dy, y, x, mean, rstd, gamma, sums, total_rows, relu, dgamma, dbeta, accumulate, want_dres=False, beta=None):
     rows, c = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    LIB.call("sc_bn_bwd_apply", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), int(total_rows), int(relu),
-             int(accumulate), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
+    LIB.call("sc_bn_bwd_apply", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(sums), int(total_rows),
+             int(relu), int(accumulate), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
     return dx, dres
 
 

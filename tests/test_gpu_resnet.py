@@ -128,6 +128,11 @@ def test_batchnorm_train(ops, relu, with_res, dtype, rows, c):
     assert rel(dg, g64.grad) < tolg and rel(db, b64.grad) < tolg
     if with_res:
         assert rel(dres, r64.grad) < tolg
+    if relu and not with_res and ops.bn_mask_from_x(c):     # the ReLU mask recomputed from x instead of read from y: the same mask, the same bits
+        sums2 = ops.bn_bwd_stats(dyd, None, xd, mean, rstd, relu, gamma.to(DEV), beta.to(DEV))
+        dg2, db2 = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        dx2, _ = ops.bn_bwd_apply(dyd, None, xd, mean, rstd, gamma.to(DEV), sums2, rows, relu, dg2, db2, False, beta=beta.to(DEV))
+        assert torch.equal(sums2, sums) and torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 def _pair(name, precision, seed=3):
