@@ -156,7 +156,7 @@ def test_resnet_tower_forward_backward(ops, name, precision):
     for k in sd:
         if k.endswith("bn3.weight") and "layer" in k:
             sd[k] = torch.rand(sd[k].shape, generator=gen) + 0.5
-    ref = ref.double()      # the oracle in fp64: in fp32 its own rounding (3-5e-6 on these gradients, tools/rn_diag.py) would be the yardstick
+    ref = ref.double()      # the oracle in fp64: in fp32 its own rounding (3-5e-6 on these gradients, measured during development) would be the yardstick
     ref.load_state_dict(sd)
     model.load_state_dict(sd)
     batch = 6
@@ -189,7 +189,7 @@ def test_resnet_tower_forward_backward(ops, name, precision):
     # fp32 bar: 2e-2, not 1e-5.  Every kernel is pinned tightly on its own above; through the whole tower a single pre-activation within
     # rounding of zero takes the other side of the ReLU than in the fp64 oracle, and in the small late layers (24 .. 384 rows) one flipped
     # element moves a BatchNorm bias gradient - and everything upstream of it - by 1/rows: torch's own fp32 run is 1e-3 .. 5e-3 off the
-    # fp64 gradients on this network for the same reason (tools/rn_diag.py).  The 1e-4 per-step loss bar is kept by the trajectory test.
+    # fp64 gradients on this network for the same reason (measured during development).  The 1e-4 per-step loss bar is kept by the trajectory test.
     worst = ("", 0.0, 0.0)
     for k, p in ref.visual.named_parameters():
         if p.grad is None:

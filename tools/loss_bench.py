@@ -3,7 +3,19 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
-from oracle.loss_head import philox_embeddings
+import numpy as np
+
+
+def philox_embeddings(seed, b, d):
+    """Deterministic unit-norm fp32 embedding pair from numpy Philox (timing inputs; the oracle is test infrastructure and is not imported here)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    out = []
+    for _ in range(2):
+        z = rng.standard_normal((b, d), dtype=np.float32)
+        out.append(z / np.linalg.norm(z, axis=1, keepdims=True))
+    return out
+
+
 from sparsify_clip_amd.loss_dispatch import step_loss
 dev = "cuda:0"
 def timed(fn, reps=5):
