@@ -344,9 +344,11 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total, b
 }
 
 // WPH = 2 (four heads per workgroup) measured 208 / 242 us at S = 77 / 50 against 250 / 276 us for WPH = 4 (profiles/r02_attention_times.txt)
-// Heads per workgroup: with two heads (256 threads, 58 / 73 KiB of LDS at S <= 64 / 80) TWO workgroups share a CU, so one stages its
-// images while the other computes; four heads per workgroup (512 threads, 116 / 146 KiB) leave one workgroup per CU.  Same waves per
-// SIMD either way.  SC_ATTN_BWD_WAVES=8 selects the four-head form (A/B).
+// Heads per workgroup: four (512 threads, 116 / 146 KiB of LDS at S <= 64 / 80, one workgroup per CU) or two (256 threads, 58 / 73 KiB,
+// two workgroups per CU, so one stages its images while the other computes).  Same waves per SIMD either way.  Stand-alone the
+// two-head form is 1 % faster (245 / 208 against 248 / 210 us); inside the training step, next to the GEMMs of the other streams, the
+// four-head form is the faster one (64.4 against 65.9 - 66.1 ms per step in one run): it is the default, SC_ATTN_BWD_WAVES=4 selects
+// the two-head form (A/B).
 template <int NT, int WPH, int WAVES>
 int launch_bwd_w(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
     constexpr int HPW = WAVES / WPH;
@@ -364,7 +366,7 @@ int launch_bwd_w(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, i
 }
 template <int NT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, int total, bool causal, float* cs_part, hipStream_t st) {
-    static const bool four_heads = [] { const char* e = getenv("SC_ATTN_BWD_WAVES"); return e && e[0] == '8'; }();
+    static const bool four_heads = [] { const char* e = getenv("SC_ATTN_BWD_WAVES"); return !(e && e[0] == '4'); }();
     if (four_heads) return launch_bwd_w<NT, 2, 8>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
     return launch_bwd_w<NT, 2, 4>(qkv, d_out, d_qkv, S, W, H, total, causal, cs_part, st);
 }
