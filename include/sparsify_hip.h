@@ -326,6 +326,12 @@ int sc_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf1
 int sc_im2col3x3(const void* x, int in_nchw_f32, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t stride, int64_t kpad,
                  void* out, void* stream);
 int sc_col2im3x3(const void* dcols, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t stride, int64_t kpad, void* dx, void* stream);
+/* The same convolution (stride 1) WITHOUT a patch matrix: an implicit GEMM over an activation with a one-pixel zero border,
+ * a_halo [batch][h+2][w+2][cin] bf16 (written by sc_bn_apply / sc_bn_bwd_apply with their halo option); b [n][9*cin] tap-major,
+ * cin = 64 * 2^j; c [batch*h*w][n] (out_dtype).  With b = the weight re-arranged [cin][(8 - tap)*cout + co] and a_halo = the bordered
+ * output gradient the same call gives the input gradient.  epi: bias / residual only (NULL = none). */
+int sc_conv3x3_bf16(const void* a_halo, const void* b, void* c, int out_dtype, int64_t batch, int64_t h, int64_t w, int64_t cin, int64_t n,
+                    const sc_gemm_epilogue* epi, void* stream);
 /* nn.AvgPool2d(k) (k = stride; h, w multiples of k) and its backward */
 int sc_avgpool_fwd(const void* x, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t k, void* y, void* stream);
 int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t k, void* dx, void* stream);

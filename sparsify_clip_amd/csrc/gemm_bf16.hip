@@ -49,6 +49,10 @@ struct GemmBf16Params {
     int group_m, group_n;      // NT 256x256: tile-walk cell (row tiles x column tiles an XCD's workgroups cover at a time)
     int half_tiles, half_m0;      // persistent NT kernel: 128x256 tiles that follow the 256x256 ones, covering rows half_m0 .. M - 1
     unsigned long long* stamps;   // diagnostic builds of the persistent NT kernel only (sc_gemm_bf16_nt_stamps): [tile][4] s_memtime values
+    // implicit 3x3 convolution (256x128 kernel only; conv_w == 0: a plain GEMM).  A is an NHWC activation with a one-pixel zero border,
+    // [batch][conv_h + 2][conv_w + 2][cin]; output row m = (b, y, x) reads, for K-tile kt = tap * kpt + kin, the 64 channels kin of
+    // pixel (b, y + tap / 3, x + tap % 3) of the bordered image - no patch matrix exists
+    int conv_w, conv_h, conv_kpt_log2;
     EpiParams epi;
 };
 
@@ -181,9 +185,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
     const bf16_t* ga[4];
     const bf16_t* gb[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ga[q] = p.A + (int64_t)min(m0 + wave * 32 + q * 8 + srow, p.M - 1) * p.lda + schunk * 8;
+    for (int q = 0; q < 4; ++q) {
+        int64_t row = min(m0 + wave * 32 + q * 8 + srow, p.M - 1);
+        if (p.conv_w) {   // compact output row (b, y, x) -> row of the centre tap's top-left neighbour (b, y, x) in the bordered image
+            const int xx = (int)(row % p.conv_w), tt = (int)(row / p.conv_w);
+            const int yy = tt % p.conv_h, bb = tt / p.conv_h;
+            row = ((int64_t)bb * (p.conv_h + 2) + yy) * (p.conv_w + 2) + xx;
+        }
+        ga[q] = p.A + row * p.lda + schunk * 8;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) gb[q] = p.B + (int64_t)min(n0 + wave * 16 + q * 8 + srow, p.N - 1) * p.ldb + schunk * 8;
+    // element offset of K-tile kt inside an A row (plain GEMM) or to the tap's pixel and channel group (implicit convolution)
+    auto a_koff = [&](int kt) -> int64_t {
+        if (!p.conv_w) return (int64_t)kt * KSTEP;
+        const int tap = kt >> p.conv_kpt_log2, kin = kt & ((1 << p.conv_kpt_log2) - 1);
+        const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+        return ((int64_t)ty * (p.conv_w + 2) + tx) * p.lda + kin * KSTEP;
+    };
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -199,7 +218,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
     do {                                                                                              \
         char* ab__ = smem + (S) * STAGE_BYTES + (wave * 32) * 128;                                    \
         char* bb__ = smem + (S) * STAGE_BYTES + A_BYTES + (wave * 16) * 128;                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(ga[q] + (KT) * KSTEP, ab__ + q * 8 * 128); \
+        const int64_t ko__ = a_koff(KT);                                                              \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(ga[q] + ko__, ab__ + q * 8 * 128);       \
         _Pragma("unroll") for (int q = 0; q < 2; ++q) glds16(gb[q] + (KT) * KSTEP, bb__ + q * 8 * 128); \
     } while (0)
 
@@ -1381,6 +1401,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_group_kernel(TnGroup g) {
     if (g.n > 3 && id >= g.prob[3].first) k = 3;
     const TnProb& q = g.prob[k];
     GemmBf16Params p;
+    p.conv_w = p.conv_h = p.conv_kpt_log2 = 0;
     p.A = q.A; p.B = q.B; p.C = q.C; p.partial = q.partial;
     p.M = q.M; p.N = q.N; p.K = g.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
     p.tiles_m = q.tiles_m; p.tiles_n = q.tiles_n; p.splits = g.splits; p.k_per_split = g.k_per_split;
@@ -1487,6 +1508,7 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
     SC_REQUIRE(epi.beta == 0.f || out_dtype == SC_F32, SC_ERR_ARG, "sc_gemm_bf16_nt: beta needs an fp32 C");
     SC_REQUIRE(!epi.colsum || (epi.colsum_ws && n % 8 == 0), SC_ERR_ARG, "sc_gemm_bf16_nt: colsum needs a workspace and N % 8 == 0");
     GemmBf16Params p;
+    p.conv_w = p.conv_h = p.conv_kpt_log2 = 0;
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)k;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -1656,6 +1678,7 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     SC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= m && ldb >= n && ldc >= n, SC_ERR_SHAPE, "sc_gemm_bf16_tn: bad leading dimension");
     SC_REQUIRE(sc_aligned(a, 16) && sc_aligned(b, 16) && sc_aligned(c, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: operands must be 16-byte aligned");
     GemmBf16Params p;
+    p.conv_w = p.conv_h = p.conv_kpt_log2 = 0;
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)r;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -1811,6 +1834,41 @@ extern "C" int sc_debug_poison_lds(void* stream) {
 }
 extern "C" int sc_debug_occupy(int blocks, int microseconds, void* stream) {
     hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, (long long)microseconds * 100, (float*)nullptr);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
+// 3x3 convolution, stride 1, padding 1, as an implicit GEMM on the 256x128 kernel (see GemmBf16Params::conv_w): no patch matrix.
+// a_halo: NHWC bf16 [batch][h + 2][w + 2][cin] with a zero one-pixel border; b: [n][9 * cin] (tap-major, cin % 64 == 0, cin a power-of-two
+// multiple of 64); c: [batch * h * w][n] bf16 or fp32, compact rows.
+extern "C" int sc_conv3x3_bf16(const void* a_halo, const void* b, void* c, int out_dtype, int64_t batch, int64_t h, int64_t w, int64_t cin, int64_t n,
+                               const sc_gemm_epilogue* e, void* stream) {
+    SC_REQUIRE(a_halo && b && c && batch > 0 && h > 0 && w > 0, SC_ERR_ARG, "sc_conv3x3_bf16: bad argument");
+    const int64_t kpt = cin / KSTEP;
+    SC_REQUIRE(cin % KSTEP == 0 && kpt >= 1 && (kpt & (kpt - 1)) == 0, SC_ERR_SHAPE, "sc_conv3x3_bf16: cin = %lld must be 64 times a power of two", (long long)cin);
+    SC_REQUIRE(n % 8 == 0 && batch * h * w < (1ll << 31), SC_ERR_SHAPE, "sc_conv3x3_bf16: bad sizes");
+    SC_REQUIRE(out_dtype == SC_BF16 || out_dtype == SC_F32, SC_ERR_DTYPE, "sc_conv3x3_bf16: bad out dtype");
+    SC_REQUIRE(sc_aligned(a_halo, 16) && sc_aligned(b, 16) && sc_aligned(c, 16), SC_ERR_ALIGN, "sc_conv3x3_bf16: operands must be 16-byte aligned");
+    EpiParams epi;
+    SC_TRY(epi_from_abi(e, SC_BF16, epi));
+    SC_REQUIRE(!epi.colsum && !epi.pre_out && !epi.dgelu_pre && epi.act == 0, SC_ERR_ARG, "sc_conv3x3_bf16: only bias / residual epilogues");
+    SC_REQUIRE(!epi.resid || epi.ld_aux % 8 == 0, SC_ERR_SHAPE, "sc_conv3x3_bf16: ld_aux must be a multiple of 8");
+    GemmBf16Params p;
+    p.A = (const bf16_t*)a_halo; p.B = (const bf16_t*)b; p.C = c;
+    p.M = (int)(batch * h * w); p.N = (int)n; p.K = (int)(9 * cin);
+    p.lda = cin; p.ldb = 9 * cin; p.ldc = n;
+    p.splits = 1; p.k_per_split = 0; p.partial = nullptr;
+    p.stamps = nullptr;
+    p.epi = epi;
+    p.epi.cs_partial = nullptr; p.epi.tickets = nullptr;
+    p.conv_w = (int)w; p.conv_h = (int)h;
+    p.conv_kpt_log2 = 0;
+    while ((1ll << p.conv_kpt_log2) < kpt) ++p.conv_kpt_log2;
+    p.tiles_m = (int)sc_cdiv(p.M, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
+    p.group_m = GROUP_M; p.group_n = GROUP_N; p.half_tiles = 0; p.half_m0 = 0;
+    const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+    if (out_dtype == SC_F32) hipLaunchKernelGGL(gemm_bf16_nt256_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_nt256_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }

@@ -537,3 +537,15 @@ def attnpool_tokens_bwd(dt, batch, hw):
     dx = torch.empty(batch * hw, c, dtype=dt.dtype, device=dt.device)
     LIB.call("sc_attnpool_tokens_bwd", ptr(dt), sc_dtype(dt.dtype), batch, hw, c, ptr(dx), stream_ptr())
     return dx
+
+
+def conv3x3_bf16(a_halo, w_taps, batch, h, w, out_dtype=torch.bfloat16, epi: GemmEpilogue | None = None):
+    """Implicit-GEMM 3x3 convolution (stride 1, padding 1): a_halo [batch, h+2, w+2, cin] bf16 with a zero border, w_taps [n, 9*cin]
+    tap-major -> [batch*h*w, n].  No patch matrix."""
+    require_gpu(a_halo, "a_halo", torch.bfloat16), require_gpu(w_taps, "w_taps", torch.bfloat16)
+    cin = a_halo.shape[-1]
+    n = w_taps.shape[0]
+    out = torch.empty(batch * h * w, n, dtype=out_dtype, device=a_halo.device)
+    LIB.call("sc_conv3x3_bf16", ptr(a_halo), ptr(w_taps), ptr(out), sc_dtype(out_dtype), batch, h, w, cin, n,
+             ctypes.byref(epi) if epi is not None else None, stream_ptr())
+    return out

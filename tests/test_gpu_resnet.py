@@ -271,3 +271,25 @@ def test_rn50_reference_yaml_runs_unchanged(ops, precision, batch):
         del tr
         torch.cuda.empty_cache()
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize("b,h,w,cin,n", [(3, 6, 10, 64, 64), (2, 7, 7, 128, 256), (5, 14, 14, 64, 136), (1, 4, 4, 256, 128)])
+def test_conv3x3_implicit_gemm(ops, b, h, w, cin, n):
+    """sc_conv3x3_bf16 (implicit GEMM over a zero-bordered NHWC activation, no patch matrix) == F.conv2d(padding=1); with the weight
+    re-arranged for the transposed convolution and the bordered output gradient as input it is the input gradient."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(b, cin, h, w, generator=g).to(torch.bfloat16).float()
+    wt = (torch.randn(n, cin, 3, 3, generator=g) * 0.05).to(torch.bfloat16).float()
+    x64 = x.double().requires_grad_(True)
+    y = F.conv2d(x64, wt.double(), padding=1)
+    halo = F.pad(x.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1)).contiguous().to(torch.bfloat16).to(DEV)          # [b, h+2, w+2, cin]
+    w_taps = wt.permute(0, 2, 3, 1).reshape(n, 9 * cin).contiguous().to(torch.bfloat16).to(DEV)
+    got = ops.conv3x3_bf16(halo, w_taps, b, h, w, out_dtype=torch.float32)
+    assert rel(got, nhwc_rows(y)) < 1e-5
+    dy = torch.randn(b, n, h, w, generator=g).to(torch.bfloat16).float()
+    y.backward(dy.double())
+    if n % 64 == 0 and (n // 64) & (n // 64 - 1) == 0:
+        dhalo = F.pad(dy.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1)).contiguous().to(torch.bfloat16).to(DEV)     # [b, h+2, w+2, n]
+        w_dx = wt.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * n).contiguous().to(torch.bfloat16).to(DEV)  # [cin][(8 - tap) * n + co]
+        dx = ops.conv3x3_bf16(dhalo, w_dx, b, h, w, out_dtype=torch.float32)
+        assert rel(dx, nhwc_rows(x64.grad)) < 1e-5
