@@ -332,6 +332,12 @@ int sc_col2im3x3(const void* dcols, int dtype, int64_t batch, int64_t h, int64_t
  * output gradient the same call gives the input gradient.  epi: bias / residual only (NULL = none). */
 int sc_conv3x3_bf16(const void* a_halo, const void* b, void* c, int out_dtype, int64_t batch, int64_t h, int64_t w, int64_t cin, int64_t n,
                     const sc_gemm_epilogue* epi, void* stream);
+/* Weight gradient of sc_conv3x3_bf16, one launch, no patch matrix: dw[cout][tap * cin + c] (tap-major, fp32) = alpha * sum over the bordered
+ * rows r of dz_halo[r][:]^T x_halo[r + shift(tap)][:] + beta * dw.  dz_halo [batch][h+2][w+2][cout] has a ZERO border; x_halo
+ * [batch][h+2][w+2][cin] additionally has w + 3 rows of zeros readable before and after the image (the shifted reads of the first and last
+ * rows).  ws: sc_gemm_bf16_tn_workspace_bytes(cout, 9 * cin, batch * (h+2) * (w+2)) bytes. */
+int sc_conv3x3_dw_bf16(const void* dz_halo, const void* x_halo, float* dw, int64_t batch, int64_t h, int64_t w, int64_t cout, int64_t cin,
+                       float alpha, float beta, void* ws, size_t ws_bytes, void* stream);
 /* nn.AvgPool2d(k) (k = stride; h, w multiples of k) and its backward */
 int sc_avgpool_fwd(const void* x, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t k, void* y, void* stream);
 int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t h, int64_t w, int64_t c, int64_t k, void* dx, void* stream);
@@ -343,18 +349,20 @@ int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t h, int64_t 
  * ranks for a synchronised BatchNorm); sc_bn_bwd_apply writes dx, optionally dres = g (the gradient of the residual input),
  * and dgamma / dbeta (+= if accumulate) from `sums` with total_rows = rows of the whole batch.  y == NULL with relu (forward WITHOUT a
  * residual, channel count a multiple of 4 that the vector kernels take): the ReLU mask is recomputed from x, gamma, beta - one tensor
- * less to read in both backward passes. */
+ * less to read in both backward passes.  halo_h / halo_w != 0 (sc_bn_apply: y; sc_bn_bwd_apply: dx): the output is written into a
+ * bordered image [batch][halo_h+2][halo_w+2][c] (interior pixels only; the caller zeroes the border) - the operand layout of
+ * sc_conv3x3_bf16. */
 size_t sc_bn_workspace_bytes(int64_t rows, int64_t c);
 int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, float* stats, void* ws, size_t ws_bytes, void* stream);
 int sc_bn_finish(const float* stats, int64_t nparts, int64_t c, int64_t rows_per_part, float eps, float momentum, float* mean, float* rstd,
                  float* running_mean, float* running_var, void* stream);
 int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                const void* res, int relu, void* y, void* stream);
+                const void* res, int relu, int64_t halo_h, int64_t halo_w, void* y, void* stream);
 int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
 int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
-                    const float* gamma, const float* beta, const float* sums, int64_t total_rows, int relu, int accumulate, void* dx, void* dres,
-                    float* dgamma, float* dbeta, void* stream);
+                    const float* gamma, const float* beta, const float* sums, int64_t total_rows, int relu, int accumulate,
+                    int64_t halo_h, int64_t halo_w, void* dx, void* dres, float* dgamma, float* dbeta, void* stream);
 /* AttentionPool2d token assembly: tokens[b][0] = mean_p x[b][p] + pos[0], tokens[b][p+1] = x[b][p] + pos[p+1]; backward w.r.t. x */
 int sc_attnpool_tokens_fwd(const void* x, int dtype, const float* pos, int64_t batch, int64_t hw, int64_t c, void* tokens, void* stream);
 int sc_attnpool_tokens_bwd(const void* dtokens, int dtype, int64_t batch, int64_t hw, int64_t c, void* dx, void* stream);

@@ -14,7 +14,7 @@ int sc_gemm_f32_launch(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k
 int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc,
                            int out_dtype, const EpiParams& epi, hipStream_t stream);
 int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
-                           float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta);
+                           float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta, int conv_w = 0);
 size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r);
 size_t sc_gemm_bf16_tn_group_ws(int nprob, const int64_t* m, const int64_t* n, int64_t r);
 int sc_gemm_bf16_tn_group_launch(int nprob, const int64_t* m, const int64_t* n, int64_t r, const void* const* a, const int64_t* lda, const void* const* b,

@@ -1061,6 +1061,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pers_kernel(GemmBf16Param
 // ds_read_b64_tr_b16 fall on 8 different 32-B slots of the 256-B bank row.
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
 
+// Weight gradient of the implicit 3x3 convolution (conv_w != 0): B is the bordered NHWC input [R][cin] (ldb = cin) and output column
+// n = tap * cin + c reads channel c of the row shifted by the tap, (ty - 1) (w + 2) + (tx - 1) rows away - an element offset per
+// staging lane, fixed for the whole contraction.  The caller keeps w + 3 finite rows either side of the image.
+__device__ __forceinline__ int tn_conv_col(int n, int cin, int w) {
+    const int tap = n / cin, c = n - tap * cin;
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+    return ((ty - 1) * (w + 2) + (tx - 1)) * cin + c;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
     const int t = threadIdx.x, lane = t & 63;
@@ -1083,6 +1092,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmBf16Params p) 
         const int c = (lane & 15) ^ tn_swz(r);
         acol[q] = min(m0 + c * 8, p.M - 8);
         bcol[q] = min(n0 + c * 8, p.N - 8);
+        if (p.conv_w) bcol[q] = tn_conv_col(bcol[q], (int)p.ldb, p.conv_w);
     }
     auto stage = [&](int buf, int kt) {
         char* abase = smem + buf * BUF_BYTES + (wave * 16) * 256;
@@ -1299,10 +1309,12 @@ __device__ __forceinline__ void tn_big_body(const GemmBf16Params& p, char* smem,
         const int r = wave * 8 + q * 2 + (lane >> 5);
         const int c = (lane & 31) ^ tn_swz(r);
         oa[q] = (unsigned)((r * p.lda + min(m0 + c * 8, p.M - 8)) * 2);
-        ob[q] = (unsigned)((r * p.ldb + min(n0 + c * 8, p.N - 8)) * 2);
+        const int nb = min(n0 + c * 8, p.N - 8);
+        // implicit convolution: the tap's row shift rides in the lane offset, kept non-negative by starting the base w + 3 rows early
+        ob[q] = p.conv_w ? (unsigned)(((r + p.conv_w + 3) * (int)p.ldb + tn_conv_col(nb, (int)p.ldb, p.conv_w)) * 2) : (unsigned)((r * p.ldb + nb) * 2);
     }
     const char* a_tile0 = (const char*)p.A + (int64_t)kt_begin * KSTEP * p.lda * 2;
-    const char* b_tile0 = (const char*)p.B + (int64_t)kt_begin * KSTEP * p.ldb * 2;
+    const char* b_tile0 = (const char*)p.B + ((int64_t)kt_begin * KSTEP - (p.conv_w ? p.conv_w + 3 : 0)) * p.ldb * 2;
     const int64_t a_step = (int64_t)KSTEP * p.lda * 2, b_step = (int64_t)KSTEP * p.ldb * 2;   // bytes per K-tile
 
     asm volatile("" ::: SC_ACC_AGPRS);   // reserve the accumulator AGPRs in the kernel descriptor
@@ -1671,14 +1683,16 @@ size_t sc_gemm_bf16_tn_ws(int64_t m, int64_t n, int64_t r) {
 }
 
 int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c,
-                           int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta) {
+                           int64_t ldc, float alpha, float beta, void* ws, size_t ws_bytes, hipStream_t stream, float* colsum_a, float colsum_beta,
+                           int conv_w) {
     SC_REQUIRE(m > 0 && n > 0 && r > 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn: empty problem");
     SC_REQUIRE(a && b && c, SC_ERR_ARG, "sc_gemm_bf16_tn: null operand");
     SC_REQUIRE(m % 8 == 0 && n % 8 == 0, SC_ERR_SHAPE, "sc_gemm_bf16_tn: M and N must be multiples of 8");
-    SC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= m && ldb >= n && ldc >= n, SC_ERR_SHAPE, "sc_gemm_bf16_tn: bad leading dimension");
+    SC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= m && (conv_w ? ldb * 9 == n : ldb >= n) && ldc >= n, SC_ERR_SHAPE,
+               "sc_gemm_bf16_tn: bad leading dimension");
     SC_REQUIRE(sc_aligned(a, 16) && sc_aligned(b, 16) && sc_aligned(c, 16), SC_ERR_ALIGN, "sc_gemm_bf16_tn: operands must be 16-byte aligned");
     GemmBf16Params p;
-    p.conv_w = p.conv_h = p.conv_kpt_log2 = 0;
+    p.conv_w = conv_w; p.conv_h = p.conv_kpt_log2 = 0;
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)b; p.C = c;
     p.M = (int)m; p.N = (int)n; p.K = (int)r;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -1873,16 +1887,27 @@ extern "C" int sc_conv3x3_bf16(const void* a_halo, const void* b, void* c, int o
     return SC_OK;
 }
 
+// Weight gradient of sc_conv3x3_bf16: dw[cout][tap * cin + c] = alpha * sum over bordered rows r of dz[r][cout] * x[r + shift(tap)][c] + beta * dw.
+// dz_halo / x_halo: bordered NHWC images [batch][h + 2][w + 2][.]; dz's border is zero (so border rows add nothing) and x_halo has
+// w + 3 rows of finite values (zeros) readable before and after the image.  Workspace: sc_gemm_bf16_tn_workspace_bytes(cout, 9 cin, rows).
+extern "C" int sc_conv3x3_dw_bf16(const void* dz_halo, const void* x_halo, float* dw, int64_t batch, int64_t h, int64_t w, int64_t cout, int64_t cin,
+                                  float alpha, float beta, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(batch > 0 && h > 0 && w > 0 && w < 32768 && cin > 0 && cin % 8 == 0, SC_ERR_SHAPE, "sc_conv3x3_dw_bf16: bad sizes");
+    SC_REQUIRE((w + 3) * cin * 4 + 64 * cin * 2 < (1ll << 31), SC_ERR_SHAPE, "sc_conv3x3_dw_bf16: row shift out of the 32-bit offset range");
+    return sc_gemm_bf16_tn_launch(cout, 9 * cin, batch * (h + 2) * (w + 2), dz_halo, cout, x_halo, cin, dw, 9 * cin, alpha, beta, ws, ws_bytes,
+                                  (hipStream_t)stream, nullptr, 0.f, (int)w);
+}
+
 extern "C" size_t sc_gemm_bf16_tn_workspace_bytes(int64_t m, int64_t n, int64_t r) {
     if (m <= 0 || n <= 0 || r <= 0) return 0;
     return sc_gemm_bf16_tn_ws(m, n, r);
 }
 extern "C" int sc_gemm_bf16_tn(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
                                float alpha, float beta, void* ws, size_t ws_bytes, void* stream) {
-    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream, nullptr, 0.f);
+    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream, nullptr, 0.f, 0);
 }
 extern "C" int sc_gemm_bf16_tn_colsum(int64_t m, int64_t n, int64_t r, const void* a, int64_t lda, const void* b, int64_t ldb, float* c, int64_t ldc,
                                       float alpha, float beta, float* colsum_a, float colsum_beta, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(colsum_a != nullptr, SC_ERR_ARG, "sc_gemm_bf16_tn_colsum: null colsum_a");
-    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream, colsum_a, colsum_beta);
+    return sc_gemm_bf16_tn_launch(m, n, r, a, lda, b, ldb, c, ldc, alpha, beta, ws, ws_bytes, (hipStream_t)stream, colsum_a, colsum_beta, 0);
 }

@@ -68,8 +68,12 @@ def gemm_bf16_nt(a, b, out_dtype=torch.bfloat16, out=None, epi: GemmEpilogue | N
     require_gpu(a, "a", torch.bfloat16), require_gpu(b, "b", torch.bfloat16)
     m, k = a.shape
     n = b.shape[0]
+    if b.shape[1] != k:      # the C ABI sees pointers and sizes only: a wrong operand here is an out-of-bounds read on the card
+        raise ScError(f"gemm_bf16_nt: a is [{m}, {k}] but b is {list(b.shape)} (expected [n, {k}])")
     if out is None:
         out = torch.empty(m, n, dtype=out_dtype, device=a.device)
+    elif tuple(out.shape) != (m, n):
+        raise ScError(f"gemm_bf16_nt: out is {list(out.shape)}, expected [{m}, {n}]")
     LIB.call("sc_gemm_bf16_nt", m, n, k, ptr(a), k, ptr(b), b.shape[1], ptr(out), n, sc_dtype(out.dtype),
              ctypes.byref(epi) if epi is not None else None, stream_ptr())
     return out
@@ -81,8 +85,12 @@ def gemm_bf16_tn(a, b, out=None, alpha=1.0, beta=0.0, colsum_out=None, colsum_be
     require_gpu(a, "a", torch.bfloat16), require_gpu(b, "b", torch.bfloat16)
     r, m = a.shape
     n = b.shape[1]
+    if b.shape[0] != r:
+        raise ScError(f"gemm_bf16_tn: a has {r} rows, b has {b.shape[0]}")
     if out is None:
         out = torch.zeros(m, n, dtype=torch.float32, device=a.device)
+    elif tuple(out.shape) != (m, n):
+        raise ScError(f"gemm_bf16_tn: out is {list(out.shape)}, expected [{m}, {n}]")
     nbytes = LIB.raw("sc_gemm_bf16_tn_workspace_bytes")(m, n, r)
     ws = _workspace(nbytes, a.device)
     if colsum_out is None:
@@ -447,24 +455,33 @@ def block_bwd(desc: BlockDesc, dx_out, dx_out_t, dx_in, dx_in_t, side_stream=Non
 def im2col3x3(x, batch, h, w, c, stride, kpad, out_dtype, nchw_images=False):
     """NHWC activation [B*H*W, C] (or the fp32 image tensor [B,C,H,W] when nchw_images) -> [B*Ho*Wo, kpad] patch matrix."""
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if x.numel() != batch * h * w * c or kpad < 9 * c:
+        raise ScError(f"im2col3x3: x has {x.numel()} elements, expected {batch} x {h} x {w} x {c} (kpad {kpad} >= {9 * c})")
     out = torch.empty(batch * ho * wo, kpad, dtype=out_dtype, device=x.device)
     LIB.call("sc_im2col3x3", ptr(x), int(nchw_images), sc_dtype(out_dtype), batch, h, w, c, stride, kpad, ptr(out), stream_ptr())
     return out
 
 
 def col2im3x3(dcols, batch, h, w, c, stride, kpad):
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if tuple(dcols.shape) != (batch * ho * wo, kpad) or kpad < 9 * c:
+        raise ScError(f"col2im3x3: dcols is {list(dcols.shape)}, expected [{batch * ho * wo}, {kpad}] with kpad >= {9 * c}")
     dx = torch.empty(batch * h * w, c, dtype=dcols.dtype, device=dcols.device)
     LIB.call("sc_col2im3x3", ptr(dcols), sc_dtype(dcols.dtype), batch, h, w, c, stride, kpad, ptr(dx), stream_ptr())
     return dx
 
 
 def avgpool_fwd(x, batch, h, w, c, k):
+    if x.numel() != batch * h * w * c:
+        raise ScError(f"avgpool_fwd: x has {x.numel()} elements, expected {batch} x {h} x {w} x {c}")
     y = torch.empty(batch * (h // k) * (w // k), c, dtype=x.dtype, device=x.device)
     LIB.call("sc_avgpool_fwd", ptr(x), sc_dtype(x.dtype), batch, h, w, c, k, ptr(y), stream_ptr())
     return y
 
 
 def avgpool_bwd(dy, batch, h, w, c, k):
+    if dy.numel() != batch * (h // k) * (w // k) * c:
+        raise ScError(f"avgpool_bwd: dy has {dy.numel()} elements, expected {batch} x {h // k} x {w // k} x {c}")
     dx = torch.empty(batch * h * w, c, dtype=dy.dtype, device=dy.device)
     LIB.call("sc_avgpool_bwd", ptr(dy), sc_dtype(dy.dtype), batch, h, w, c, k, ptr(dx), stream_ptr())
     return dx
@@ -491,10 +508,29 @@ def bn_finish(stats, nparts, c, rows_per_part, running_mean=None, running_var=No
     return mean, rstd
 
 
-def bn_apply(x, mean, rstd, gamma, beta, relu, res=None):
+def halo_buffer(batch, h, w, c, dtype, device):
+    """Zeroed bordered NHWC image [batch, h+2, w+2, c] inside a flat buffer with (w + 3) slack rows at both ends (the shifted views of the
+    per-tap weight-gradient GEMMs stay inside it).  -> (flat buffer, the image view)."""
+    slack, rows = w + 3, batch * (h + 2) * (w + 2)
+    flat = torch.zeros(rows + 2 * slack, c, dtype=dtype, device=device)
+    return flat, flat[slack:slack + rows]
+
+
+def _check_halo(halo, rows, c, what):
+    if halo is None:
+        return
+    img, h, w = halo
+    if rows % (h * w) or img.numel() != (rows // (h * w)) * (h + 2) * (w + 2) * c or img.dtype != torch.bfloat16 and img.dtype != torch.float32:
+        raise ScError(f"{what}: the bordered image has {img.numel()} elements, expected [{rows // (h * w)}, {h + 2}, {w + 2}, {c}]")
+
+
+def bn_apply(x, mean, rstd, gamma, beta, relu, res=None, halo=None):
+    """halo = (image view of halo_buffer, h, w): write y into the bordered image instead of a compact [rows, c] tensor."""
     rows, c = x.shape
-    y = torch.empty_like(x)
-    LIB.call("sc_bn_apply", ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), int(relu), ptr(y), stream_ptr())
+    y = torch.empty_like(x) if halo is None else halo[0]
+    hh, hw = (0, 0) if halo is None else (halo[1], halo[2])
+    _check_halo(halo, rows, c, "bn_apply")
+    LIB.call("sc_bn_apply", ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), int(relu), hh, hw, ptr(y), stream_ptr())
     return y
 
 
@@ -516,12 +552,14 @@ def bn_bwd_stats(dy, y, x, mean, rstd, relu, gamma=None, beta=None):
     return sums
 
 
-def bn_bwd_apply(dy, y, x, mean, rstd, gamma, sums, total_rows, relu, dgamma, dbeta, accumulate, want_dres=False, beta=None):
+def bn_bwd_apply(dy, y, x, mean, rstd, gamma, sums, total_rows, relu, dgamma, dbeta, accumulate, want_dres=False, beta=None, halo=None):
     rows, c = x.shape
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if halo is None else halo[0]
+    hh, hw = (0, 0) if halo is None else (halo[1], halo[2])
+    _check_halo(halo, rows, c, "bn_bwd_apply")
     dres = torch.empty_like(x) if want_dres else None
     LIB.call("sc_bn_bwd_apply", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(sums), int(total_rows),
-             int(relu), int(accumulate), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
+             int(relu), int(accumulate), hh, hw, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
     return dx, dres
 
 
@@ -545,7 +583,27 @@ def conv3x3_bf16(a_halo, w_taps, batch, h, w, out_dtype=torch.bfloat16, epi: Gem
     require_gpu(a_halo, "a_halo", torch.bfloat16), require_gpu(w_taps, "w_taps", torch.bfloat16)
     cin = a_halo.shape[-1]
     n = w_taps.shape[0]
+    if a_halo.numel() != batch * (h + 2) * (w + 2) * cin or w_taps.shape[1] != 9 * cin:
+        raise ScError(f"conv3x3_bf16: a_halo has {a_halo.numel()} elements for [{batch}, {h + 2}, {w + 2}, {cin}], w_taps is {list(w_taps.shape)}")
     out = torch.empty(batch * h * w, n, dtype=out_dtype, device=a_halo.device)
     LIB.call("sc_conv3x3_bf16", ptr(a_halo), ptr(w_taps), ptr(out), sc_dtype(out_dtype), batch, h, w, cin, n,
              ctypes.byref(epi) if epi is not None else None, stream_ptr())
+    return out
+
+
+def conv3x3_dw_bf16(dz_img, x_flat, batch, h, w, out=None, beta=0.0):
+    """Weight gradient of conv3x3_bf16 in one launch: dz_img = the image view of a halo_buffer holding dz (zero border), x_flat = the FLAT
+    halo_buffer of the convolution's input (its zero slack rows are read by the shifted taps) -> [cout, 9 * cin] fp32, tap-major."""
+    require_gpu(dz_img, "dz_img", torch.bfloat16), require_gpu(x_flat, "x_flat", torch.bfloat16)
+    rows, slack = batch * (h + 2) * (w + 2), w + 3
+    cout, cin = dz_img.shape[-1], x_flat.shape[-1]
+    if dz_img.numel() != rows * cout or x_flat.numel() != (rows + 2 * slack) * cin:
+        raise ScError(f"conv3x3_dw_bf16: dz_img has {dz_img.numel()} elements, x_flat {x_flat.numel()}; expected {rows} x {cout} and "
+                      f"{rows + 2 * slack} x {cin} (halo_buffer)")
+    if out is None:
+        out = torch.zeros(cout, 9 * cin, dtype=torch.float32, device=dz_img.device)
+    elif tuple(out.shape) != (cout, 9 * cin):
+        raise ScError(f"conv3x3_dw_bf16: out is {list(out.shape)}, expected [{cout}, {9 * cin}]")
+    ws = _workspace(LIB.raw("sc_gemm_bf16_tn_workspace_bytes")(cout, 9 * cin, rows), dz_img.device)
+    LIB.call("sc_conv3x3_dw_bf16", ptr(dz_img), ptr(x_flat[slack:]), ptr(out), batch, h, w, cout, cin, 1.0, float(beta), ptr(ws), ws.numel(), stream_ptr())
     return out

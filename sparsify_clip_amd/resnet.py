@@ -14,6 +14,7 @@ The backward is written out by hand (no autograd), like the ViT towers'.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -131,7 +132,11 @@ class ResNetVisual:
                 gp[:, : cv.kdim].copy_(g)
                 g = gp
             g = g.to(dt).contiguous()
-            self.gw[cv.name] = (g, g.t().contiguous())
+            if self.implicit(cv):   # input gradient = the same implicit GEMM over the bordered output gradient: [cin][(8 - tap) * cout + co]
+                gdx = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cv.cin, 9 * cv.cout).to(dt).contiguous()
+                self.gw[cv.name] = (g, gdx)
+            else:
+                self.gw[cv.name] = (g, g.t().contiguous())
         c = self.cfeat
         qkv = torch.cat([m.param(f"visual.attnpool.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], dim=0)
         self.gw["attnpool.qkv"] = (qkv.to(dt).contiguous(), qkv.t().to(dt).contiguous())
@@ -139,6 +144,15 @@ class ResNetVisual:
 
     def kpad(self, cv):
         return _pad64(cv.kdim) if self.m.dtype == torch.bfloat16 else cv.kdim
+
+    def implicit(self, cv):
+        """A bottleneck's 3x3 (stride 1; the stem keeps im2col), bf16, 64 * 2^j input AND output channels: the implicit-GEMM convolution (sc_conv3x3_bf16) on bordered activations
+        - forward and input gradient without a patch matrix, the weight gradient as nine GEMMs over shifted views of the bordered input.
+        SC_RN_IM2COL=1 keeps the im2col path (A/B)."""
+        def ok(c):
+            return c % 64 == 0 and (c // 64) & (c // 64 - 1) == 0
+        return (cv.name.endswith(".conv2") and ".layer" in cv.name and cv.k == 3 and cv.stride == 1 and self.m.dtype == torch.bfloat16 and ok(cv.cin) and ok(cv.cout) and ops.bn_mask_from_x(cv.cin)
+                and os.environ.get("SC_RN_IM2COL", "0") != "1")
 
     # ------------------------------------------------------------------------------------------ GEMM helpers (compute dtype)
     def _nt(self, x, w, resid=None):            # x [R, K] @ w [N, K]^T (+ resid [R, N])
@@ -177,7 +191,7 @@ class ResNetVisual:
             raise ScError(f"{cv.name}: the bf16 path needs channel counts that are multiples of 64 (got {cv.cin}); use --precision fp32")
         return self._nt(x, g), h, w
 
-    def _bn_fwd(self, cv, z, relu, res=None):
+    def _bn_fwd(self, cv, z, relu, res=None, halo=None):
         rows, c = z.shape
         m = self.m
         stats = ops.bn_stats(z)
@@ -193,21 +207,21 @@ class ResNetVisual:
         else:   # evaluation: the running statistics (sparsify_clip.py:540 model.eval())
             mean = m.buffers[cv.bn + ".running_mean"]
             rstd = torch.rsqrt(m.buffers[cv.bn + ".running_var"] + 1e-5)
-        y = ops.bn_apply(z, mean, rstd, m.param(cv.bn + ".weight"), m.param(cv.bn + ".bias"), relu, res)
+        y = ops.bn_apply(z, mean, rstd, m.param(cv.bn + ".weight"), m.param(cv.bn + ".bias"), relu, res, halo=halo)
         return y, mean, rstd
 
-    def _bn_bwd(self, cv, dy, y, z, mean, rstd, relu, acc, want_dres=False):
+    def _bn_bwd(self, cv, dy, y, z, mean, rstd, relu, acc, want_dres=False, halo=None):
         m = self.m
         rows = z.shape[0]
         gamma, beta = m.param(cv.bn + ".weight"), m.param(cv.bn + ".bias")
-        if relu and not want_dres and ops.bn_mask_from_x(cv.cout):
+        if relu and not want_dres and (y is None or ops.bn_mask_from_x(cv.cout)):
             y = None         # no residual entered this BatchNorm: the ReLU mask is recomputed from z, one tensor less to read in both passes
         sums = ops.bn_bwd_stats(dy, y, z, mean, rstd, relu, gamma, beta)
         world = D.world_size() if D.active() else 1
         if world > 1:
             D.all_reduce_sum_(sums)
         return ops.bn_bwd_apply(dy, y, z, mean, rstd, gamma, sums, rows * world, relu, m.grad(cv.bn + ".weight"), m.grad(cv.bn + ".bias"), acc,
-                                want_dres, beta=beta)
+                                want_dres, beta=beta, halo=halo)
 
     def _conv_bwd(self, cv, dz, x_in, batch, h, w, acc, need_dx=True, images=None, resid=None):
         """dz: gradient of the convolution output rows; x_in: the convolution's input rows (or images).  Writes the weight gradient;
@@ -235,6 +249,16 @@ class ResNetVisual:
             return ops.col2im3x3(dcols, batch, h, w, cv.cin, cv.stride, kpad)
         return dcols
 
+    def _conv3x3_dw(self, cv, dz_img, x_flat, batch, h, w, acc):
+        """Weight gradient of an implicit convolution, one TN GEMM whose B operand is the bordered input read through the nine tap shifts
+        (sc_conv3x3_dw_bf16; the zero border of dz makes the border rows contribute nothing)."""
+        dwg = ops.conv3x3_dw_bf16(dz_img, x_flat, batch, h, w).view(cv.cout, 3, 3, cv.cin).permute(0, 3, 1, 2)
+        gw = self.m.grad(cv.name + ".weight")
+        if acc:
+            ops.axpy_(gw, 1.0, dwg.contiguous())
+        else:
+            gw.copy_(dwg)                   # layout change only ([Cout, taps, Cin] -> [Cout, Cin, 3, 3])
+
     # ------------------------------------------------------------------------------------------ tower
     def forward(self, images):
         m = self.m
@@ -255,8 +279,15 @@ class ResNetVisual:
         for p, c1, c2, c3, down, stride in self.blocks:
             rec = {"x": x, "h": h, "w": w}
             z1, _, _ = self._conv_fwd(c1, x, batch, h, w)
-            y1, m1, r1 = self._bn_fwd(c1, z1, True)
-            z2, _, _ = self._conv_fwd(c2, y1, batch, h, w)
+            if self.implicit(c2):      # bn1 writes straight into the bordered image conv2 reads; no compact y1, no patch matrix
+                flat1, img1 = ops.halo_buffer(batch, h, w, c1.cout, m.dtype, z1.device)
+                _, m1, r1 = self._bn_fwd(c1, z1, True, halo=(img1, h, w))
+                y1 = None
+                rec["y1_halo"] = flat1
+                z2 = ops.conv3x3_bf16(img1, self.gw[c2.name][0], batch, h, w)
+            else:
+                y1, m1, r1 = self._bn_fwd(c1, z1, True)
+                z2, _, _ = self._conv_fwd(c2, y1, batch, h, w)
             y2, m2, r2 = self._bn_fwd(c2, z2, True)
             a2 = ops.avgpool_fwd(y2, batch, h, w, c2.cout, stride) if stride > 1 else y2
             ho, wo = h // stride, w // stride
@@ -328,8 +359,15 @@ class ResNetVisual:
             dz3, didn = self._bn_bwd(c3, dx, rec["y3"], rec["z3"], rec["m3"], rec["r3"], True, acc, want_dres=True)
             da2 = self._conv_bwd(c3, dz3, rec["a2"], batch, ho, wo, acc)
             dy2 = ops.avgpool_bwd(da2, batch, h, w, c2.cout, stride) if stride > 1 else da2
-            dz2, _ = self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc)
-            dy1 = self._conv_bwd(c2, dz2, rec["y1"], batch, h, w, acc)
+            if self.implicit(c2):
+                flatd, imgd = ops.halo_buffer(batch, h, w, c2.cout, m.dtype, dx.device)
+                self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc, halo=(imgd, h, w))      # dz2 into the bordered image
+                dy1 = ops.conv3x3_bf16(imgd, self.gw[c2.name][1], batch, h, w)
+                self._conv3x3_dw(c2, imgd, rec["y1_halo"], batch, h, w, acc)
+                del flatd
+            else:
+                dz2, _ = self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc)
+                dy1 = self._conv_bwd(c2, dz2, rec["y1"], batch, h, w, acc)
             dz1, _ = self._bn_bwd(c1, dy1, rec["y1"], rec["z1"], rec["m1"], rec["r1"], True, acc)
             if down is not None:
                 dzd, _ = self._bn_bwd(down, didn, None, rec["zd"], rec["md"], rec["rd"], False, acc)

@@ -293,3 +293,51 @@ def test_conv3x3_implicit_gemm(ops, b, h, w, cin, n):
         w_dx = wt.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * n).contiguous().to(torch.bfloat16).to(DEV)  # [cin][(8 - tap) * n + co]
         dx = ops.conv3x3_bf16(dhalo, w_dx, b, h, w, out_dtype=torch.float32)
         assert rel(dx, nhwc_rows(x64.grad)) < 1e-5
+
+
+@pytest.mark.parametrize("b,h,w,c", [(2, 7, 7, 64), (3, 5, 9, 128), (1, 4, 4, 2048)])
+def test_batchnorm_bordered_outputs(ops, b, h, w, c):
+    """sc_bn_apply / sc_bn_bwd_apply writing into the bordered image the implicit convolution reads: the interior carries the same bits as the
+    compact output, the one-pixel border and the slack rows stay zero."""
+    g = torch.Generator().manual_seed(11)
+    rows = b * h * w
+    x = (torch.randn(rows, c, generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    dy = torch.randn(rows, c, generator=g).to(torch.bfloat16).to(DEV)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    mean, rstd = ops.bn_finish(ops.bn_stats(x), 1, c, rows)
+    y = ops.bn_apply(x, mean, rstd, gamma, beta, True)
+    flat, img = ops.halo_buffer(b, h, w, c, torch.bfloat16, DEV)
+    ops.bn_apply(x, mean, rstd, gamma, beta, True, halo=(img, h, w))
+    want = torch.zeros(b, h + 2, w + 2, c, dtype=torch.bfloat16, device=DEV)
+    want[:, 1:-1, 1:-1] = y.view(b, h, w, c)
+    assert torch.equal(img.view(b, h + 2, w + 2, c), want)
+    assert not flat[: w + 3].any() and not flat[-(w + 3):].any()
+    sums = ops.bn_bwd_stats(dy, None, x, mean, rstd, True, gamma, beta)
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    dx, _ = ops.bn_bwd_apply(dy, None, x, mean, rstd, gamma, sums, rows, True, dg, db, False, beta=beta)
+    flat2, img2 = ops.halo_buffer(b, h, w, c, torch.bfloat16, DEV)
+    dg2, db2 = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    ops.bn_bwd_apply(dy, None, x, mean, rstd, gamma, sums, rows, True, dg2, db2, False, beta=beta, halo=(img2, h, w))
+    want[:, 1:-1, 1:-1] = dx.view(b, h, w, c)
+    assert torch.equal(img2.view(b, h + 2, w + 2, c), want)
+    assert torch.equal(dg2, dg) and torch.equal(db2, db)
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(3, 6, 10, 64, 64), (2, 7, 7, 128, 256), (64, 14, 14, 64, 136), (1, 4, 4, 256, 128), (64, 8, 8, 512, 512)])
+def test_conv3x3_implicit_weight_gradient(ops, b, h, w, cin, cout):
+    """sc_conv3x3_dw_bf16 (one TN GEMM over the bordered images, the tap shift in the B operand's addressing) == the weight gradient of
+    F.conv2d(padding=1); covers the small kernel (ragged contraction length) and the large one (rows a multiple of 64, >= 6 tiles)."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(b, cin, h, w, generator=g).to(torch.bfloat16).float()
+    dz = (torch.randn(b, cout, h, w, generator=g) * 0.1).to(torch.bfloat16).float()
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dz.double())
+    xflat, ximg = ops.halo_buffer(b, h, w, cin, torch.bfloat16, DEV)
+    ximg.view(b, h + 2, w + 2, cin)[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1).to(torch.bfloat16).to(DEV)
+    _, dimg = ops.halo_buffer(b, h, w, cout, torch.bfloat16, DEV)
+    dimg.view(b, h + 2, w + 2, cout)[:, 1:-1, 1:-1] = dz.permute(0, 2, 3, 1).to(torch.bfloat16).to(DEV)
+    got = ops.conv3x3_dw_bf16(dimg, xflat, b, h, w).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    assert rel(got, wt.grad) < 1e-5
+    acc = torch.ones(cout, 9 * cin, device=DEV)
+    ops.conv3x3_dw_bf16(dimg, xflat, b, h, w, out=acc, beta=1.0)
+    assert rel(acc.view(cout, 3, 3, cin).permute(0, 3, 1, 2), wt.grad + 1) < 1e-5
