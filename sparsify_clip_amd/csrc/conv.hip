@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int BN_MAX_BLOCKS = 256;
+constexpr int BN_MAX_BLOCKS = 1024;
 
 // ---------------------------------------------------------------- 3x3 convolution lowering (padding 1, stride 1 or 2)
 // out[(b, yo, xo)][tap * C + c] = x[b][yo*stride + ky - 1][xo*stride + kx - 1][c]  (tap = 3 ky + kx; 0 outside; columns >= 9C are 0)
@@ -322,23 +322,39 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T*
         k = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c);
         if (relu && !y) { gm = *(const f32x4*)(gamma + c); bt = *(const f32x4*)(beta + c); }
     }
-    for (int64_t r = r0 + lr; r < r1; r += rpi) {
-        const f32x4 xv = io<T>::ld4(x + r * C + c);
+    auto add = [&](const f32x4& xv, f32x4 g, const f32x4& yv) {
         if (KIND == 0) {
             const f32x4 d = xv - k;
             a += d;
             b += d * d;
         } else {
-            f32x4 g = io<T>::ld4(dy + r * C + c);
             const f32x4 xh = (xv - k) * rs;
             if (relu) {   // the ReLU's mask: from the stored output, or (no residual in the forward) recomputed from x - one tensor less to read
-                const f32x4 yv = y ? io<T>::ld4(y + r * C + c) : xh * gm + bt;
+                const f32x4 m = y ? yv : xh * gm + bt;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+                for (int j = 0; j < 4; ++j) g[j] = m[j] > 0.f ? g[j] : 0.f;
             }
             a += g;
             b += g * xh;
         }
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0 + lr;
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {   // four rows in flight per lane: the loads first, then the (ordered) accumulation
+        f32x4 xv[4], gv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = (r + u * rpi) * C + c;
+            xv[u] = io<T>::ld4(x + e);
+            gv[u] = KIND == 1 ? io<T>::ld4(dy + e) : zero;
+            yv[u] = KIND == 1 && relu && y ? io<T>::ld4(y + e) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(xv[u], gv[u], yv[u]);
+    }
+    for (; r < r1; r += rpi) {
+        const int64_t e = r * C + c;
+        add(io<T>::ld4(x + e), KIND == 1 ? io<T>::ld4(dy + e) : zero, KIND == 1 && relu && y ? io<T>::ld4(y + e) : zero);
     }
     sm[0][t] = a; sm[1][t] = b;
     __syncthreads();
@@ -348,24 +364,25 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T*
         *(f32x4*)(partial + ((int64_t)blockIdx.y * 2 + 1) * C + c) = b;
     }
 }
-// out[0..C) = sum_b partial[b][0], out[C..2C) = sum_b partial[b][1] (fixed order: four slices of the blocks per channel, then the slices);
+// out[0..C) = sum_b partial[b][0], out[C..2C) = sum_b partial[b][1] (fixed order: sixteen slices of the blocks per channel, then the slices);
 // shift != null: out[2C..3C) = shift values x[0][c] (forward statistics)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_collect_v_kernel(const float* partial, int nblocks, int C, const T* shift_row, float* out) {
-    __shared__ float sm[2][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float sm[2][16][16];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;      // 16 channels per block, 16 slices of the row blocks per channel
+    const int c = blockIdx.x * 16 + cl;
     float a = 0.f, b = 0.f;
     if (c < C)
-        for (int k = sl; k < nblocks; k += 4) {
+        for (int k = sl; k < nblocks; k += 16) {
             a += partial[((int64_t)k * 2 + 0) * C + c];
             b += partial[((int64_t)k * 2 + 1) * C + c];
         }
     sm[0][sl][cl] = a; sm[1][sl][cl] = b;
     __syncthreads();
     if (sl == 0 && c < C) {
-        out[c] = ((sm[0][0][cl] + sm[0][1][cl]) + sm[0][2][cl]) + sm[0][3][cl];
-        out[C + c] = ((sm[1][0][cl] + sm[1][1][cl]) + sm[1][2][cl]) + sm[1][3][cl];
+        for (int j = 1; j < 16; ++j) { a += sm[0][j][cl]; b += sm[1][j][cl]; }
+        out[c] = a;
+        out[C + c] = b;
         if (shift_row) out[2 * C + c] = io<T>::ld(shift_row + c);
     }
 }
@@ -527,7 +544,7 @@ extern "C" int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, fl
         hipLaunchKernelGGL((bn_partial_v4_kernel<T, 0>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)nullptr, \
                            (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, (int)c, lpr, \
                            rpb, 0, (float*)ws);                                                                                            \
-        hipLaunchKernelGGL(bn_collect_v_kernel<T>, dim3((unsigned)sc_cdiv(c, 64)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const T*)x, stats); \
+        hipLaunchKernelGGL(bn_collect_v_kernel<T>, dim3((unsigned)sc_cdiv(c, 16)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const T*)x, stats); \
     } while (0)
     const int lpr = vec_ok(8) ? bn_lpr(c) : 0;
     if (lpr) SC_DT(dtype, BSV(bf16_t), BSV(float));
@@ -578,7 +595,7 @@ extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int
     const int lpr = vec_ok(32) ? bn_lpr(c) : 0;
     if (lpr) {
         SC_DT(dtype, BBV(bf16_t), BBV(float));
-        hipLaunchKernelGGL(bn_collect_v_kernel<float>, dim3((unsigned)sc_cdiv(c, 64)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const float*)nullptr, sums);
+        hipLaunchKernelGGL(bn_collect_v_kernel<float>, dim3((unsigned)sc_cdiv(c, 16)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const float*)nullptr, sums);
     } else {
         SC_DT(dtype, BB(bf16_t), BB(float));
         hipLaunchKernelGGL(bn_bwd_collect_kernel, dim3((unsigned)sc_cdiv(c, 256)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, sums);
