@@ -398,22 +398,42 @@ __device__ __forceinline__ int64_t halo_elem(int64_t e, int C, int hh, int hw) {
     const int64_t b = t / hh;
     return (((b * (hh + 2) + yy + 1) * (hw + 2)) + xx + 1) * C + c;
 }
-template <typename T>
+// INV: the grid stride is a multiple of C, so a thread stays on its four channels for the whole loop and the per-channel vectors are
+// loaded once (the launchers check it); otherwise they are re-read (L2 / cache hits) every iteration.
+template <typename T, bool INV>
 __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                                           const T* res, int64_t n4, int C, int relu, int hh, int hw, T* y) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
-        f32x4 v = (io<T>::ld4(x + i * 4) - mu) * rs * g + bt;
-        if (res) v += io<T>::ld4(res + i * 4);
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    f32x4 mu, rs, g, bt;      // the expression below is the one the backward kernels re-evaluate for the ReLU mask: keep them identical
+    auto params = [&](int c) {
+        mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c);
+        g = *(const f32x4*)(gamma + c); bt = *(const f32x4*)(beta + c);
+    };
+    if (INV) params((int)((i0 * 4) % C));
+    auto one = [&](int64_t i, f32x4 xv, f32x4 rv) {
+        f32x4 v = (xv - mu) * rs * g + bt;
+        if (res) v += rv;
         if (relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         io<T>::st4(y + halo_elem(i * 4, C, hh, hw), v);
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = i0;
+    if (INV)
+        for (; i + step < n4; i += 2 * step) {      // two quads in flight per lane
+            const f32x4 x0 = io<T>::ld4(x + i * 4), x1 = io<T>::ld4(x + (i + step) * 4);
+            const f32x4 r0 = res ? io<T>::ld4(res + i * 4) : zero, r1 = res ? io<T>::ld4(res + (i + step) * 4) : zero;
+            one(i, x0, r0);
+            one(i + step, x1, r1);
+        }
+    for (; i < n4; i += step) {
+        if (!INV) params((int)((i * 4) % C));
+        one(i, io<T>::ld4(x + i * 4), res ? io<T>::ld4(res + i * 4) : zero);
     }
 }
-template <typename T>
+template <typename T, bool INV>
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const T* y, const T* x, const float* mean, const float* rstd, const float* gamma,
                                                               const float* beta, const float* sums, float count, int64_t n4, int C, int relu, int accumulate,
                                                               int hh, int hw, T* dx, T* dres, float* dgamma, float* dbeta) {
@@ -423,19 +443,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const
             dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sums[c];
         }
     const float inv = 1.0f / count;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        f32x4 g = io<T>::ld4(dy + i * 4);
-        const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), gm = *(const f32x4*)(gamma + c);
-        const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
-        const f32x4 xh = (io<T>::ld4(x + i * 4) - mu) * rs;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    f32x4 mu, rs, gm, bt, sg, sgx;
+    auto params = [&](int c) {
+        mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); gm = *(const f32x4*)(gamma + c);
+        sg = *(const f32x4*)(sums + c); sgx = *(const f32x4*)(sums + C + c);
+        bt = relu && !y ? *(const f32x4*)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    if (INV) params((int)((i0 * 4) % C));
+    auto one = [&](int64_t i, f32x4 g, f32x4 xv, f32x4 yv) {
+        const f32x4 xh = (xv - mu) * rs;
         if (relu) {
-            const f32x4 yv = y ? io<T>::ld4(y + i * 4) : xh * gm + *(const f32x4*)(beta + c);
+            const f32x4 m = y ? yv : xh * gm + bt;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+            for (int j = 0; j < 4; ++j) g[j] = m[j] > 0.f ? g[j] : 0.f;
         }
         io<T>::st4(dx + halo_elem(i * 4, C, hh, hw), gm * rs * (g - sg * inv - xh * sgx * inv));
         if (dres) io<T>::st4(dres + i * 4, g);
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool rd_y = relu && y;
+    int64_t i = i0;
+    if (INV)
+        for (; i + step < n4; i += 2 * step) {
+            const f32x4 g0 = io<T>::ld4(dy + i * 4), g1 = io<T>::ld4(dy + (i + step) * 4);
+            const f32x4 x0 = io<T>::ld4(x + i * 4), x1 = io<T>::ld4(x + (i + step) * 4);
+            const f32x4 y0 = rd_y ? io<T>::ld4(y + i * 4) : zero, y1 = rd_y ? io<T>::ld4(y + (i + step) * 4) : zero;
+            one(i, g0, x0, y0);
+            one(i + step, g1, x1, y1);
+        }
+    for (; i < n4; i += step) {
+        if (!INV) params((int)((i * 4) % C));
+        one(i, io<T>::ld4(dy + i * 4), io<T>::ld4(x + i * 4), rd_y ? io<T>::ld4(y + i * 4) : zero);
     }
 }
 
@@ -571,10 +610,12 @@ extern "C" int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, co
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n, (int)c, relu, (T*)y)
-#define BAV(T) hipLaunchKernelGGL(bn_apply_v4_kernel<T>, dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n / 4, (int)c, relu, (int)halo_h, (int)halo_w, (T*)y)
+#define BAV_(T, INV) hipLaunchKernelGGL((bn_apply_v4_kernel<T, INV>), dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n / 4, (int)c, relu, (int)halo_h, (int)halo_w, (T*)y)
+#define BAV(T) do { if (((int64_t)stream_grid(n / 4) * 1024) % c == 0) BAV_(T, true); else BAV_(T, false); } while (0)
     if (c % 4 == 0 && vec_ok(16)) SC_DT(dtype, BAV(bf16_t), BAV(float));
     else SC_DT(dtype, BA(bf16_t), BA(float));
 #undef BAV
+#undef BAV_
 #undef BA
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -616,10 +657,12 @@ extern "C" int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, (float)total_rows, n, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
-#define BAV(T) hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<T>, dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, beta, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (int)halo_h, (int)halo_w, (T*)dx, (T*)dres, dgamma, dbeta)
+#define BAV_(T, INV) hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<T, INV>), dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, beta, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (int)halo_h, (int)halo_w, (T*)dx, (T*)dres, dgamma, dbeta)
+#define BAV(T) do { if (((int64_t)stream_grid(n / 4) * 1024) % c == 0) BAV_(T, true); else BAV_(T, false); } while (0)
     if (c % 4 == 0 && vec_ok(64)) SC_DT(dtype, BAV(bf16_t), BAV(float));
     else SC_DT(dtype, BA(bf16_t), BA(float));
 #undef BAV
+#undef BAV_
 #undef BA
     SC_CHECK_LAUNCH();
     return SC_OK;

@@ -1466,12 +1466,15 @@ int tn_env() {
     static const int v = [] { const char* e = getenv("SC_GEMM_TN"); return (e && e[0] == '1') ? 128 : 0; }();
     return v;
 }
+// Contraction splits of the TN kernels: enough workgroups to fill the chip even for a one-tile weight gradient over millions of rows (a
+// ResNet stem / first-stage convolution: [32..64] x [64..576] outputs, 0.8 - 3.2 M rows - HBM-bound, so every CU has to stream).
+constexpr int TN_MAX_SPLITS = 256;
 void tn_plan_small(int64_t m, int64_t n, int64_t r, int& kind, int& splits) {
     const int64_t nk = sc_cdiv(r, KSTEP);
     int64_t s = sc_cdiv(768, sc_cdiv(m, TILE) * sc_cdiv(n, TILE));
     const int64_t cap = nk / 4 > 1 ? nk / 4 : 1;
     if (s > cap) s = cap;
-    if (s > 32) s = 32;
+    if (s > TN_MAX_SPLITS) s = TN_MAX_SPLITS;
     kind = TN_SMALL;
     splits = (int)(s < 1 ? 1 : s);
 }
@@ -1488,7 +1491,7 @@ void tn_plan(int64_t m, int64_t n, int64_t r, bool colsum, int& kind, int& split
     }
     const int64_t cap = nk / 4 > 1 ? nk / 4 : 1;
     if (s > cap) s = cap;
-    if (s > 32) s = 32;
+    if (s > TN_MAX_SPLITS) s = TN_MAX_SPLITS;
     splits = (int)(s < 1 ? 1 : s);
 }
 
