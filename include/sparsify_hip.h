@@ -306,6 +306,12 @@ int sc_image_resample_normalize(const uint8_t* src, const int64_t* offset, const
                                 float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b,
                                 void* tmp, float* out, void* stream);
 
+/* HOST function (no GPU call): item k = rows[k] rows of row_bytes[k] bytes, src_row_stride[k] bytes apart, starting at src[k] (a crop
+ * box inside a decoded image) -> dst + dst_offset[k], contiguous; `threads` host threads share the items.  Fills the pinned staging
+ * buffer of sc_image_resample_normalize's H2D copy (the reference's DataLoader workers + default collate, sparsify_clip.py:1060-1065). */
+int sc_host_gather_rows(int64_t n, const void* const* src, const int64_t* src_row_stride, const int64_t* rows, const int64_t* row_bytes,
+                        void* dst, const int64_t* dst_offset, int64_t dst_bytes, int threads);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.AdamW defaults over one flat fp32 parameter buffer (sparsify_clip.py:730, :962/966).
  * p *= 1 - lr*wd; m,v moments; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `step` is the 1-based step count.

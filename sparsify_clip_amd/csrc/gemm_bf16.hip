@@ -1440,13 +1440,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(TnGroup g, int
     *(f32x4*)cp = v;
 }
 
-// C = alpha * sum_s partial[s] + beta * C   (fixed order); optionally also cs_out = cs_beta * cs_out + sum_s cs_partial[s]
+// C = alpha * sum_s partial[s] + beta * C   (fixed order); optionally also cs_out = cs_beta * cs_out + sum_s cs_partial[s].
+// SL = slices of the split range per output quad (threads t % SL of a block; combined through LDS in slice order): a one-tile
+// weight gradient split 256 ways has 16 K outputs and 16 MB of partials - with one thread per quad 16 workgroups would read them.
+template <int SL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, int splits, int64_t mn, int n, float* c, int64_t ldc,
                                                             float alpha, float beta, const float* cs_partial, float* cs_out, int m_len, float cs_beta) {
-    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= mn) return;
-    f32x4 s = *(const f32x4*)(partial + i4);
-    for (int k = 1; k < splits; ++k) s += *(const f32x4*)(partial + (int64_t)k * mn + i4);
+    __shared__ f32x4 sm[SL > 1 ? 256 : 1];
+    constexpr int QPB = 256 / SL;      // output quads per block
+    const int sl = threadIdx.x / QPB, q = threadIdx.x % QPB;
+    const int64_t i4 = ((int64_t)blockIdx.x * QPB + q) * 4;
+    const bool live = i4 < mn;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int k = sl; k < splits; k += SL) s += *(const f32x4*)(partial + (int64_t)k * mn + i4);
+    if (SL > 1) {
+        sm[threadIdx.x] = s;
+        __syncthreads();
+        if (sl != 0) return;
+        for (int j = 1; j < SL; ++j) s += sm[j * QPB + q];
+    }
+    if (!live) return;
     float* cp = c + (i4 / n) * ldc + (i4 % n);
     f32x4 v = s * alpha;
     if (beta != 0.f) v += *(const f32x4*)cp * beta;
@@ -1727,8 +1741,12 @@ int sc_gemm_bf16_tn_launch(int64_t m, int64_t n, int64_t r, const void* a, int64
     SC_CHECK_LAUNCH();
     if (p.splits > 1) {
         const int64_t mn = m * n;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)sc_cdiv(mn / 4, 256)), dim3(256), 0, stream, p.partial, p.splits, mn, (int)n, c, ldc,
-                           alpha, beta, p.cs_partial, colsum_a, (int)m, colsum_beta);
+#define SKR(SL) hipLaunchKernelGGL(splitk_reduce_kernel<SL>, dim3((unsigned)sc_cdiv(mn / 4, 256 / SL)), dim3(256), 0, stream, p.partial, p.splits, mn, (int)n, \
+                                   c, ldc, alpha, beta, p.cs_partial, colsum_a, (int)m, colsum_beta)
+        if (p.splits >= 64) SKR(16);
+        else if (p.splits >= 16) SKR(4);
+        else SKR(1);
+#undef SKR
         SC_CHECK_LAUNCH();
     }
     if (kind == TN_BIG && colsum_a)   // stream-ordered behind the reduction, so the partial-slab workspace is free again

@@ -24,18 +24,28 @@ class HashTokenizer:
     def __init__(self, context_length=CTX, vocab=VOCAB):
         self.context_length, self.vocab = context_length, vocab
         self.sot, self.eot = vocab - 2, vocab - 1
+        self._ids = {}      # word -> id (the hash is a pure function of the word; the table only saves recomputing it)
 
     def __call__(self, texts):
         if isinstance(texts, str):
             texts = [texts]
-        out = torch.zeros(len(texts), self.context_length, dtype=torch.long)
+        ctx, ids_of, mod = self.context_length, self._ids, self.sot - 1
+        if len(ids_of) > (1 << 20):
+            ids_of.clear()
+        out = np.zeros((len(texts), ctx), dtype=np.int64)
         for i, t in enumerate(texts):
-            ids = [self.sot] + [1 + zlib.crc32(w.encode("utf-8")) % (self.sot - 1) for w in t.lower().split()] + [self.eot]
-            if len(ids) > self.context_length:
-                ids = ids[: self.context_length]
+            ids = [self.sot]
+            for w in t.lower().split():
+                v = ids_of.get(w)
+                if v is None:
+                    v = ids_of[w] = 1 + zlib.crc32(w.encode("utf-8")) % mod
+                ids.append(v)
+            ids.append(self.eot)
+            if len(ids) > ctx:
+                ids = ids[:ctx]
                 ids[-1] = self.eot
-            out[i, : len(ids)] = torch.tensor(ids)
-        return out
+            out[i, : len(ids)] = ids
+        return torch.from_numpy(out)
 
 
 def caption_length(tokens) -> int:

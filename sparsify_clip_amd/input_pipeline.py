@@ -18,10 +18,12 @@ COCO itself is not available offline: `CocoCaptionsDataset` reads the standard d
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import math
 import os
 import queue
+import sys
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -29,7 +31,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import ScError
+from ._lib import LIB, ScError
 
 MEAN = (0.48145466, 0.4578275, 0.40821073)   # reference :1003
 STD = (0.26862954, 0.26130258, 0.27577711)   # reference :1004
@@ -67,6 +69,7 @@ class SyntheticCocoDataset:
     """Seeded stand-in with COCO's shape statistics: uint8 images (landscape 640x480 / portrait 480x640 / 640x427 ...) drawn
     from a small pool of distinct random images, five captions per image."""
 
+    in_memory = True      # __getitem__ is a table lookup
     SIZES = [(480, 640), (640, 480), (427, 640), (640, 427), (375, 500), (500, 375)]
     WORDS = "a the man woman dog cat table street standing sitting on with of and red large small two people holding plate train".split()
 
@@ -156,7 +159,10 @@ class DeviceAugLoader:
 
     def _assemble(self, batch_index: int, order, pool: ThreadPoolExecutor, pinned: torch.Tensor) -> _HostBatch:
         ids = order[batch_index * self.bs:(batch_index + 1) * self.bs]
-        items = list(pool.map(lambda i: self.ds[int(i)], ids))              # decode in parallel
+        if getattr(self.ds, "in_memory", False):                            # nothing to decode: 1024 pool tasks would only pass the GIL around
+            items = [self.ds[int(i)] for i in ids]
+        else:
+            items = list(pool.map(lambda i: self.ds[int(i)], ids))          # decode in parallel (Pillow releases the GIL)
         rng = self.batch_rng(batch_index)
         samples = [self._geometry(img, caps, rng) for img, caps in items]   # cheap scalar draws, sequential = deterministic
         hb = _HostBatch()
@@ -175,14 +181,16 @@ class DeviceAugLoader:
         hb.captions = [s[2] for s in samples]
         if self.tokenizer is not None:
             hb.captions = self.tokenizer(hb.captions).pin_memory()
-        dst = pinned.numpy()
-
-        def put(k):
-            a = samples[k][0]
-            o = int(hb.offset[k])
-            dst[o:o + a.size].reshape(a.shape)[...] = a      # strided crop view -> contiguous staging bytes (numpy releases the GIL)
-
-        list(pool.map(put, range(hb.n)))
+        # strided crop views -> contiguous staging bytes: one native call (sc_host_gather_rows, C++ threads, GIL released by ctypes)
+        crops = [s[0] if s[0].strides[1:] == (3, 1) else np.ascontiguousarray(s[0]) for s in samples]
+        n = hb.n
+        src = (ctypes.c_void_p * n)(*[a.ctypes.data for a in crops])
+        stride = np.array([a.strides[0] for a in crops], dtype=np.int64)
+        rows = np.ascontiguousarray(hb.dims[:, 4], dtype=np.int64)
+        row_bytes = hb.dims[:, 5].astype(np.int64) * 3
+        LIB.call("sc_host_gather_rows", n, src, stride.ctypes.data, rows.ctypes.data, row_bytes.ctypes.data, pinned.data_ptr(),
+                 hb.offset.ctypes.data, pinned.numel(), max(1, self.workers // 2))      # half the threads: the copy is memory-bound, the
+        #                                                                                       training thread needs a core to enqueue the step
         hb.pixels = pinned
         return hb
 
@@ -220,6 +228,11 @@ class DeviceAugLoader:
             except BaseException as e:      # surfaces in the consumer
                 q.put(e)
 
+        # The assembly thread runs ~10-25 ms of pure Python per batch.  Every kernel launch of the training thread drops the GIL (ctypes,
+        # torch) and, with CPython's default 5 ms switch interval, waits up to 5 ms to get it back while the assembly thread is in Python:
+        # measured 42 ms instead of 5 ms to enqueue a step (tools/pipeline_bench.py).  A 50 us interval bounds each hand-back instead.
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 5e-5))
         th = threading.Thread(target=producer, daemon=True)
         th.start()
         try:
@@ -268,6 +281,7 @@ class DeviceAugLoader:
                 yield images, caps
             self.epoch += 1
         finally:
+            sys.setswitchinterval(old_interval)
             stop.set()
             while th.is_alive():
                 try:

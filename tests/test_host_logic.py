@@ -257,3 +257,35 @@ def test_input_pipeline_host_side(tmp_path):
     syn = IP.SyntheticCocoDataset(10, seed=1, pool=4)
     img, caps = syn[7]
     assert img.dtype == np.uint8 and img.ndim == 3 and len(caps) == 5 and syn[7][1] == caps
+
+
+def test_host_gather_rows_native():
+    """sc_host_gather_rows (a HOST function of the library: C++ threads, no GPU call) packs strided crop views into one contiguous
+    staging buffer exactly as numpy would, for any thread count; items that would overrun the buffer are refused."""
+    import ctypes
+    from sparsify_clip_amd._lib import LIB, ScError
+    rng = np.random.Generator(np.random.Philox(5))
+    imgs = [rng.integers(0, 256, size=(int(rng.integers(20, 60)), int(rng.integers(20, 60)), 3), dtype=np.uint8) for _ in range(37)]
+    crops = []
+    for im in imgs:
+        h, w = im.shape[:2]
+        bh, bw = int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1))
+        t, l = int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1))
+        crops.append(im[t:t + bh, l:l + bw])
+    want = np.concatenate([np.ascontiguousarray(c).reshape(-1) for c in crops])
+    sizes = np.array([c.size for c in crops], dtype=np.int64)
+    offset = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    n = len(crops)
+    src = (ctypes.c_void_p * n)(*[c.ctypes.data for c in crops])
+    stride = np.array([c.strides[0] for c in crops], dtype=np.int64)
+    rows = np.array([c.shape[0] for c in crops], dtype=np.int64)
+    row_bytes = np.array([c.shape[1] * 3 for c in crops], dtype=np.int64)
+    for threads in (1, 3, 16):
+        dst = np.zeros(want.size + 7, dtype=np.uint8)
+        LIB.call("sc_host_gather_rows", n, src, stride.ctypes.data, rows.ctypes.data, row_bytes.ctypes.data, dst.ctypes.data, offset.ctypes.data,
+                 dst.size, threads)
+        assert np.array_equal(dst[: want.size], want) and not dst[want.size:].any()
+    with pytest.raises(ScError):
+        LIB.call("sc_host_gather_rows", n, src, stride.ctypes.data, rows.ctypes.data, row_bytes.ctypes.data, dst.ctypes.data, offset.ctypes.data,
+                 want.size - 1, 2)
+    LIB.call("sc_host_gather_rows", 0, None, None, None, None, None, None, 0, 4)      # an empty batch is a no-op
