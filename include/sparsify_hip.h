@@ -356,19 +356,20 @@ int sc_avgpool_bwd(const void* dy, int dtype, int64_t batch, int64_t h, int64_t 
  * and dgamma / dbeta (+= if accumulate) from `sums` with total_rows = rows of the whole batch.  y == NULL with relu (forward WITHOUT a
  * residual, channel count a multiple of 4 that the vector kernels take): the ReLU mask is recomputed from x, gamma, beta - one tensor
  * less to read in both backward passes.  halo_h / halo_w != 0 (sc_bn_apply: y; sc_bn_bwd_apply: dx): the output is written into a
- * bordered image [batch][halo_h+2][halo_w+2][c] (interior pixels only; the caller zeroes the border) - the operand layout of
- * sc_conv3x3_bf16. */
+ * bordered image [batch][halo_h+2][halo_w+2][halo_c] with halo_c >= c channels (interior pixels and the first c channels only; the
+ * caller zeroes the rest: a 32-channel activation inside a 64-channel image meets sc_conv3x3_bf16's cin = 64 * 2^j) - the operand
+ * layout of sc_conv3x3_bf16.  halo_h == halo_w == 0: compact rows, halo_c ignored. */
 size_t sc_bn_workspace_bytes(int64_t rows, int64_t c);
 int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, float* stats, void* ws, size_t ws_bytes, void* stream);
 int sc_bn_finish(const float* stats, int64_t nparts, int64_t c, int64_t rows_per_part, float eps, float momentum, float* mean, float* rstd,
                  float* running_mean, float* running_var, void* stream);
 int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                const void* res, int relu, int64_t halo_h, int64_t halo_w, void* y, void* stream);
+                const void* res, int relu, int64_t halo_h, int64_t halo_w, int64_t halo_c, void* y, void* stream);
 int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
 int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, const float* sums, int64_t total_rows, int relu, int accumulate,
-                    int64_t halo_h, int64_t halo_w, void* dx, void* dres, float* dgamma, float* dbeta, void* stream);
+                    int64_t halo_h, int64_t halo_w, int64_t halo_c, void* dx, void* dres, float* dgamma, float* dbeta, void* stream);
 /* AttentionPool2d token assembly: tokens[b][0] = mean_p x[b][p] + pos[0], tokens[b][p+1] = x[b][p] + pos[p+1]; backward w.r.t. x */
 int sc_attnpool_tokens_fwd(const void* x, int dtype, const float* pos, int64_t batch, int64_t hw, int64_t c, void* tokens, void* stream);
 int sc_attnpool_tokens_bwd(const void* dtokens, int dtype, int64_t batch, int64_t hw, int64_t c, void* dx, void* stream);

@@ -30,6 +30,8 @@ CONFIGS = {
                     ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
     "test-rn64": dict(embed_dim=128, image_size=64, v_kind="resnet", v_layers=(1, 1, 1, 1), v_width=128,
                       ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
+    "test-rn32": dict(embed_dim=64, image_size=64, v_kind="resnet", v_layers=(1, 1, 1, 1), v_width=64,      # RN50's channel counts (32-channel stem)
+                      ctx=16, vocab=512, t_width=64, t_layers=1, t_heads=1),
     "tiny": dict(embed_dim=64, image_size=64, patch=32, v_width=128, v_layers=2, v_heads=2,
                  ctx=16, vocab=512, t_width=64, t_layers=2, t_heads=1),
     "test-small": dict(embed_dim=128, image_size=224, patch=32, v_width=128, v_layers=1, v_heads=2,

@@ -386,9 +386,10 @@ __global__ __launch_bounds__(256) void bn_collect_v_kernel(const float* partial,
         if (shift_row) out[2 * C + c] = io<T>::ld(shift_row + c);
     }
 }
-// halo_w != 0: the output goes to a zero-bordered NHWC image [B][halo_h + 2][halo_w + 2][C] (row r = (b, y, x) -> pixel (y + 1, x + 1)),
-// the layout sc_conv3x3_bf16 reads; the border itself is zeroed by the caller
-__device__ __forceinline__ int64_t halo_elem(int64_t e, int C, int hh, int hw) {
+// halo_w != 0: the output goes to a zero-bordered NHWC image [B][halo_h + 2][halo_w + 2][CS] (row r = (b, y, x) -> pixel (y + 1, x + 1)),
+// the layout sc_conv3x3_bf16 reads; CS >= C is the image's channel count (a 32-channel activation inside a 64-channel image, the
+// implicit GEMM's K granularity); the border and the channels >= C are zeroed by the caller
+__device__ __forceinline__ int64_t halo_elem(int64_t e, int C, int hh, int hw, int CS) {
     if (!hw) return e;
     const int64_t r = e / C;
     const int c = (int)(e - r * C);
@@ -396,13 +397,13 @@ __device__ __forceinline__ int64_t halo_elem(int64_t e, int C, int hh, int hw) {
     const int64_t t = r / hw;
     const int yy = (int)(t % hh);
     const int64_t b = t / hh;
-    return (((b * (hh + 2) + yy + 1) * (hw + 2)) + xx + 1) * C + c;
+    return (((b * (hh + 2) + yy + 1) * (hw + 2)) + xx + 1) * CS + c;
 }
 // INV: the grid stride is a multiple of C, so a thread stays on its four channels for the whole loop and the per-channel vectors are
 // loaded once (the launchers check it); otherwise they are re-read (L2 / cache hits) every iteration.
 template <typename T, bool INV>
 __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                                          const T* res, int64_t n4, int C, int relu, int hh, int hw, T* y) {
+                                                          const T* res, int64_t n4, int C, int relu, int hh, int hw, int hc, T* y) {
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
     f32x4 mu, rs, g, bt;      // the expression below is the one the backward kernels re-evaluate for the ReLU mask: keep them identical
     auto params = [&](int c) {
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* x, const floa
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        io<T>::st4(y + halo_elem(i * 4, C, hh, hw), v);
+        io<T>::st4(y + halo_elem(i * 4, C, hh, hw, hc), v);
     };
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int64_t i = i0;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* x, const floa
 template <typename T, bool INV>
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const T* y, const T* x, const float* mean, const float* rstd, const float* gamma,
                                                               const float* beta, const float* sums, float count, int64_t n4, int C, int relu, int accumulate,
-                                                              int hh, int hw, T* dx, T* dres, float* dgamma, float* dbeta) {
+                                                              int hh, int hw, int hc, T* dx, T* dres, float* dgamma, float* dbeta) {
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += 256) {
             dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sums[C + c];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* dy, const
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = m[j] > 0.f ? g[j] : 0.f;
         }
-        io<T>::st4(dx + halo_elem(i * 4, C, hh, hw), gm * rs * (g - sg * inv - xh * sgx * inv));
+        io<T>::st4(dx + halo_elem(i * 4, C, hh, hw, hc), gm * rs * (g - sg * inv - xh * sgx * inv));
         if (dres) io<T>::st4(dres + i * 4, g);
     };
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -603,14 +604,14 @@ extern "C" int sc_bn_finish(const float* stats, int64_t nparts, int64_t c, int64
     return SC_OK;
 }
 extern "C" int sc_bn_apply(const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                           const void* res, int relu, int64_t halo_h, int64_t halo_w, void* y, void* stream) {
+                           const void* res, int relu, int64_t halo_h, int64_t halo_w, int64_t halo_c, void* y, void* stream) {
     SC_REQUIRE(x && y && mean && rstd && gamma && beta && rows > 0 && c > 0, SC_ERR_ARG, "sc_bn_apply: bad argument");
-    SC_REQUIRE((halo_h == 0) == (halo_w == 0) && (halo_w == 0 || (c % 4 == 0 && vec_ok(16) && rows % (halo_h * halo_w) == 0)), SC_ERR_SHAPE,
-               "sc_bn_apply: the bordered output needs c %% 4 == 0 and rows = batch * halo_h * halo_w");
+    SC_REQUIRE((halo_h == 0) == (halo_w == 0) && (halo_w == 0 || (c % 4 == 0 && vec_ok(16) && rows % (halo_h * halo_w) == 0 && halo_c >= c && halo_c % 4 == 0)),
+               SC_ERR_SHAPE, "sc_bn_apply: the bordered output needs c %% 4 == 0, rows = batch * halo_h * halo_w and halo_c >= c");
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n, (int)c, relu, (T*)y)
-#define BAV_(T, INV) hipLaunchKernelGGL((bn_apply_v4_kernel<T, INV>), dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n / 4, (int)c, relu, (int)halo_h, (int)halo_w, (T*)y)
+#define BAV_(T, INV) hipLaunchKernelGGL((bn_apply_v4_kernel<T, INV>), dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)res, n / 4, (int)c, relu, (int)halo_h, (int)halo_w, (int)halo_c, (T*)y)
 #define BAV(T) do { if (((int64_t)stream_grid(n / 4) * 1024) % c == 0) BAV_(T, true); else BAV_(T, false); } while (0)
     if (c % 4 == 0 && vec_ok(16)) SC_DT(dtype, BAV(bf16_t), BAV(float));
     else SC_DT(dtype, BA(bf16_t), BA(float));
@@ -648,16 +649,16 @@ extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int
 }
 extern "C" int sc_bn_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int64_t rows, int64_t c, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, const float* sums, int64_t total_rows, int relu, int accumulate,
-                               int64_t halo_h, int64_t halo_w, void* dx, void* dres, float* dgamma, float* dbeta, void* stream) {
+                               int64_t halo_h, int64_t halo_w, int64_t halo_c, void* dx, void* dres, float* dgamma, float* dbeta, void* stream) {
     SC_REQUIRE(dy && x && dx && sums && mean && rstd && gamma && dgamma && dbeta && rows > 0 && c > 0 && total_rows >= rows, SC_ERR_ARG,
                "sc_bn_bwd_apply: bad argument");
-    SC_REQUIRE((halo_h == 0) == (halo_w == 0) && (halo_w == 0 || (c % 4 == 0 && vec_ok(64) && rows % (halo_h * halo_w) == 0)), SC_ERR_SHAPE,
-               "sc_bn_bwd_apply: the bordered dx needs c %% 4 == 0 and rows = batch * halo_h * halo_w");
+    SC_REQUIRE((halo_h == 0) == (halo_w == 0) && (halo_w == 0 || (c % 4 == 0 && vec_ok(64) && rows % (halo_h * halo_w) == 0 && halo_c >= c && halo_c % 4 == 0)),
+               SC_ERR_SHAPE, "sc_bn_bwd_apply: the bordered dx needs c %% 4 == 0, rows = batch * halo_h * halo_w and halo_c >= c");
     SC_REQUIRE(!relu || y || (beta && c % 4 == 0 && vec_ok(64)), SC_ERR_ARG, "sc_bn_bwd_apply: ReLU needs the stored output y (or beta, with c % 4 == 0)");
     const int64_t n = rows * c;
     hipStream_t st = (hipStream_t)stream;
 #define BA(T) hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, (float)total_rows, n, (int)c, relu, accumulate, (T*)dx, (T*)dres, dgamma, dbeta)
-#define BAV_(T, INV) hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<T, INV>), dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, beta, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (int)halo_h, (int)halo_w, (T*)dx, (T*)dres, dgamma, dbeta)
+#define BAV_(T, INV) hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<T, INV>), dim3(stream_grid(n / 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, beta, sums, (float)total_rows, n / 4, (int)c, relu, accumulate, (int)halo_h, (int)halo_w, (int)halo_c, (T*)dx, (T*)dres, dgamma, dbeta)
 #define BAV(T) do { if (((int64_t)stream_grid(n / 4) * 1024) % c == 0) BAV_(T, true); else BAV_(T, false); } while (0)
     if (c % 4 == 0 && vec_ok(64)) SC_DT(dtype, BAV(bf16_t), BAV(float));
     else SC_DT(dtype, BA(bf16_t), BA(float));

@@ -520,17 +520,18 @@ def _check_halo(halo, rows, c, what):
     if halo is None:
         return
     img, h, w = halo
-    if rows % (h * w) or img.numel() != (rows // (h * w)) * (h + 2) * (w + 2) * c or img.dtype != torch.bfloat16 and img.dtype != torch.float32:
-        raise ScError(f"{what}: the bordered image has {img.numel()} elements, expected [{rows // (h * w)}, {h + 2}, {w + 2}, {c}]")
+    cs = img.shape[-1]      # the image's channel count: >= c (a 32-channel activation inside a 64-channel image; the rest stays zero)
+    if rows % (h * w) or cs < c or img.numel() != (rows // (h * w)) * (h + 2) * (w + 2) * cs or img.dtype != torch.bfloat16 and img.dtype != torch.float32:
+        raise ScError(f"{what}: the bordered image has {img.numel()} elements, expected [{rows // (h * w)}, {h + 2}, {w + 2}, >= {c}]")
 
 
 def bn_apply(x, mean, rstd, gamma, beta, relu, res=None, halo=None):
     """halo = (image view of halo_buffer, h, w): write y into the bordered image instead of a compact [rows, c] tensor."""
     rows, c = x.shape
     y = torch.empty_like(x) if halo is None else halo[0]
-    hh, hw = (0, 0) if halo is None else (halo[1], halo[2])
+    hh, hw, hc = (0, 0, 0) if halo is None else (halo[1], halo[2], halo[0].shape[-1])
     _check_halo(halo, rows, c, "bn_apply")
-    LIB.call("sc_bn_apply", ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), int(relu), hh, hw, ptr(y), stream_ptr())
+    LIB.call("sc_bn_apply", ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), int(relu), hh, hw, hc, ptr(y), stream_ptr())
     return y
 
 
@@ -555,11 +556,11 @@ def bn_bwd_stats(dy, y, x, mean, rstd, relu, gamma=None, beta=None):
 def bn_bwd_apply(dy, y, x, mean, rstd, gamma, sums, total_rows, relu, dgamma, dbeta, accumulate, want_dres=False, beta=None, halo=None):
     rows, c = x.shape
     dx = torch.empty_like(x) if halo is None else halo[0]
-    hh, hw = (0, 0) if halo is None else (halo[1], halo[2])
+    hh, hw, hc = (0, 0, 0) if halo is None else (halo[1], halo[2], halo[0].shape[-1])
     _check_halo(halo, rows, c, "bn_bwd_apply")
     dres = torch.empty_like(x) if want_dres else None
     LIB.call("sc_bn_bwd_apply", ptr(dy), ptr(y), ptr(x), sc_dtype(x.dtype), rows, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(sums), int(total_rows),
-             int(relu), int(accumulate), hh, hw, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
+             int(relu), int(accumulate), hh, hw, hc, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr())
     return dx, dres
 
 

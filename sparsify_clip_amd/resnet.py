@@ -132,9 +132,13 @@ class ResNetVisual:
                 gp[:, : cv.kdim].copy_(g)
                 g = gp
             g = g.to(dt).contiguous()
-            if self.implicit(cv):   # input gradient = the same implicit GEMM over the bordered output gradient: [cin][(8 - tap) * cout + co]
-                gdx = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cv.cin, 9 * cv.cout).to(dt).contiguous()
-                self.gw[cv.name] = (g, gdx)
+            if self.implicit(cv):   # tap-major over the bordered image's channels (zero columns for the padding channels); the input
+                ci, co = _pad64(cv.cin), _pad64(cv.cout)      # gradient is the same implicit GEMM over the bordered output gradient
+                g = torch.zeros(cv.cout, 3, 3, ci, dtype=torch.float32, device=w.device)
+                g[..., : cv.cin] = w.permute(0, 2, 3, 1)
+                gdx = torch.zeros(cv.cin, 3, 3, co, dtype=torch.float32, device=w.device)      # [cin][(8 - tap) * co + cout]
+                gdx[..., : cv.cout] = w.flip(2, 3).permute(1, 2, 3, 0)
+                self.gw[cv.name] = (g.reshape(cv.cout, 9 * ci).to(dt).contiguous(), gdx.reshape(cv.cin, 9 * co).to(dt).contiguous())
             else:
                 self.gw[cv.name] = (g, g.t().contiguous())
         c = self.cfeat
@@ -146,15 +150,16 @@ class ResNetVisual:
         return _pad64(cv.kdim) if self.m.dtype == torch.bfloat16 else cv.kdim
 
     def implicit(self, cv):
-        """A bottleneck's 3x3 (stride 1; the stem keeps im2col), bf16, 64 * 2^j input AND output channels: the implicit-GEMM convolution (sc_conv3x3_bf16) on bordered activations
-        - forward and input gradient without a patch matrix, the weight gradient as nine GEMMs over shifted views of the bordered input.
-        SC_RN_IM2COL=1 keeps the im2col path (A/B)."""
+        """A 3x3, stride-1 convolution of a bottleneck or of the stem (conv2, conv3) in bf16 whose channel counts, rounded up to 64, are
+        64 * 2^j (a 32-channel stem activation travels inside a 64-channel image, the other half zero): the implicit-GEMM convolution
+        (sc_conv3x3_bf16) on bordered activations - forward and input gradient without a patch matrix, the weight gradient as one TN
+        GEMM over shifted views of the bordered input.  SC_RN_IM2COL=1 keeps the im2col path (A/B)."""
         def ok(c):
-            return c % 64 == 0 and (c // 64) & (c // 64 - 1) == 0
-        return (cv.name.endswith(".conv2") and ".layer" in cv.name and cv.k == 3 and cv.stride == 1 and self.m.dtype == torch.bfloat16 and ok(cv.cin) and ok(cv.cout) and ops.bn_mask_from_x(cv.cin)
-                and os.environ.get("SC_RN_IM2COL", "0") != "1")
-
-    # ------------------------------------------------------------------------------------------ GEMM helpers (compute dtype)
+            p = _pad64(c) // 64
+            return c % 8 == 0 and 2 * c >= 64 * p and p & (p - 1) == 0
+        placed = (cv.name.endswith(".conv2") and ".layer" in cv.name) or cv.name in ("visual.conv2", "visual.conv3")
+        return (placed and cv.k == 3 and cv.stride == 1 and self.m.dtype == torch.bfloat16 and ok(cv.cin) and ok(cv.cout)
+                and ops.bn_mask_from_x(cv.cin) and os.environ.get("SC_RN_IM2COL", "0") != "1")
     def _nt(self, x, w, resid=None):            # x [R, K] @ w [N, K]^T (+ resid [R, N])
         epi = None
         if self.m.dtype == torch.bfloat16:
@@ -252,7 +257,8 @@ class ResNetVisual:
     def _conv3x3_dw(self, cv, dz_img, x_flat, batch, h, w, acc):
         """Weight gradient of an implicit convolution, one TN GEMM whose B operand is the bordered input read through the nine tap shifts
         (sc_conv3x3_dw_bf16; the zero border of dz makes the border rows contribute nothing)."""
-        dwg = ops.conv3x3_dw_bf16(dz_img, x_flat, batch, h, w).view(cv.cout, 3, 3, cv.cin).permute(0, 3, 1, 2)
+        co, ci = dz_img.shape[-1], x_flat.shape[-1]       # the images' channel counts (>= the convolution's)
+        dwg = ops.conv3x3_dw_bf16(dz_img, x_flat, batch, h, w).view(co, 3, 3, ci)[: cv.cout, :, :, : cv.cin].permute(0, 3, 1, 2)
         gw = self.m.grad(cv.name + ".weight")
         if acc:
             ops.axpy_(gw, 1.0, dwg.contiguous())
@@ -267,12 +273,20 @@ class ResNetVisual:
             self.refresh_weights()
         S = self.saved = {"batch": batch, "images": images, "stem": [], "blocks": [], "cols": {}}
         h = w = self.image_size
-        x = None
+        x = x_halo = None
         for i, cv in enumerate(self.stem):
-            z, ho, wo = self._conv_fwd(cv, x, batch, h, w, images=images if i == 0 else None)
-            y, mean, rstd = self._bn_fwd(cv, z, True)
-            S["stem"].append((x, z, y, mean, rstd, h, w))
-            x, h, w = y, ho, wo
+            if self.implicit(cv):      # its input arrived as a bordered image
+                z, ho, wo = ops.conv3x3_bf16(x_halo[1], self.gw[cv.name][0], batch, h, w), h, w
+            else:
+                z, ho, wo = self._conv_fwd(cv, x, batch, h, w, images=images if i == 0 else None)
+            if i + 1 < len(self.stem) and self.implicit(self.stem[i + 1]):
+                out_halo = ops.halo_buffer(batch, ho, wo, _pad64(cv.cout), m.dtype, z.device)
+                y, (_, mean, rstd) = None, self._bn_fwd(cv, z, True, halo=(out_halo[1], ho, wo))
+            else:
+                out_halo = None
+                y, mean, rstd = self._bn_fwd(cv, z, True)
+            S["stem"].append((x, x_halo, z, y, mean, rstd, h, w))
+            x, x_halo, h, w = y, out_halo, ho, wo
         S["stem_hw"] = (h, w)
         x = ops.avgpool_fwd(x, batch, h, w, self.width, 2)
         h, w = h // 2, w // 2
@@ -280,7 +294,7 @@ class ResNetVisual:
             rec = {"x": x, "h": h, "w": w}
             z1, _, _ = self._conv_fwd(c1, x, batch, h, w)
             if self.implicit(c2):      # bn1 writes straight into the bordered image conv2 reads; no compact y1, no patch matrix
-                flat1, img1 = ops.halo_buffer(batch, h, w, c1.cout, m.dtype, z1.device)
+                flat1, img1 = ops.halo_buffer(batch, h, w, _pad64(c1.cout), m.dtype, z1.device)
                 _, m1, r1 = self._bn_fwd(c1, z1, True, halo=(img1, h, w))
                 y1 = None
                 rec["y1_halo"] = flat1
@@ -360,7 +374,7 @@ class ResNetVisual:
             da2 = self._conv_bwd(c3, dz3, rec["a2"], batch, ho, wo, acc)
             dy2 = ops.avgpool_bwd(da2, batch, h, w, c2.cout, stride) if stride > 1 else da2
             if self.implicit(c2):
-                flatd, imgd = ops.halo_buffer(batch, h, w, c2.cout, m.dtype, dx.device)
+                flatd, imgd = ops.halo_buffer(batch, h, w, _pad64(c2.cout), m.dtype, dx.device)
                 self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc, halo=(imgd, h, w))      # dz2 into the bordered image
                 dy1 = ops.conv3x3_bf16(imgd, self.gw[c2.name][1], batch, h, w)
                 self._conv3x3_dw(c2, imgd, rec["y1_halo"], batch, h, w, acc)
@@ -383,7 +397,13 @@ class ResNetVisual:
         dx = ops.avgpool_bwd(dx, batch, h, w, self.width, 2)
         for i in reversed(range(len(self.stem))):
             cv = self.stem[i]
-            x_in, z, y, mean, rstd, hi, wi = S["stem"][i]
+            x_in, x_halo, z, y, mean, rstd, hi, wi = S["stem"][i]
+            if self.implicit(cv):
+                _, imgd = ops.halo_buffer(batch, hi, wi, _pad64(cv.cout), m.dtype, dx.device)
+                self._bn_bwd(cv, dx, y, z, mean, rstd, True, acc, halo=(imgd, hi, wi))
+                dx = ops.conv3x3_bf16(imgd, self.gw[cv.name][1], batch, hi, wi)
+                self._conv3x3_dw(cv, imgd, x_halo[0], batch, hi, wi, acc)
+                continue
             dz, _ = self._bn_bwd(cv, dx, y, z, mean, rstd, True, acc)
             dx = self._conv_bwd(cv, dz, x_in, batch, hi, wi, acc, need_dx=i > 0, images=S["images"] if i == 0 else None)
         if m.comm is not None:

@@ -144,7 +144,7 @@ def _pair(name, precision, seed=3):
     return ref, model
 
 
-@pytest.mark.parametrize("name,precision", [("test-rn", "fp32"), ("test-rn64", "bf16")])
+@pytest.mark.parametrize("name,precision", [("test-rn", "fp32"), ("test-rn64", "bf16"), ("test-rn32", "bf16")])
 def test_resnet_tower_forward_backward(ops, name, precision):
     """The HIP ModifiedResNet tower against the oracle on identical weights: embeddings, every parameter gradient, the BatchNorm
     running statistics after the step; then evaluation mode (running statistics) against the oracle's eval forward."""
@@ -295,10 +295,10 @@ def test_conv3x3_implicit_gemm(ops, b, h, w, cin, n):
         assert rel(dx, nhwc_rows(x64.grad)) < 1e-5
 
 
-@pytest.mark.parametrize("b,h,w,c", [(2, 7, 7, 64), (3, 5, 9, 128), (1, 4, 4, 2048)])
-def test_batchnorm_bordered_outputs(ops, b, h, w, c):
+@pytest.mark.parametrize("b,h,w,c,cs", [(2, 7, 7, 64, 64), (3, 5, 9, 128, 128), (1, 4, 4, 2048, 2048), (3, 6, 5, 32, 64)])
+def test_batchnorm_bordered_outputs(ops, b, h, w, c, cs):
     """sc_bn_apply / sc_bn_bwd_apply writing into the bordered image the implicit convolution reads: the interior carries the same bits as the
-    compact output, the one-pixel border and the slack rows stay zero."""
+    compact output, the one-pixel border, the slack rows and the channels beyond c (a 32-channel activation in a 64-channel image) stay zero."""
     g = torch.Generator().manual_seed(11)
     rows = b * h * w
     x = (torch.randn(rows, c, generator=g) + 0.5).to(torch.bfloat16).to(DEV)
@@ -306,20 +306,20 @@ def test_batchnorm_bordered_outputs(ops, b, h, w, c):
     gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
     mean, rstd = ops.bn_finish(ops.bn_stats(x), 1, c, rows)
     y = ops.bn_apply(x, mean, rstd, gamma, beta, True)
-    flat, img = ops.halo_buffer(b, h, w, c, torch.bfloat16, DEV)
+    flat, img = ops.halo_buffer(b, h, w, cs, torch.bfloat16, DEV)
     ops.bn_apply(x, mean, rstd, gamma, beta, True, halo=(img, h, w))
-    want = torch.zeros(b, h + 2, w + 2, c, dtype=torch.bfloat16, device=DEV)
-    want[:, 1:-1, 1:-1] = y.view(b, h, w, c)
-    assert torch.equal(img.view(b, h + 2, w + 2, c), want)
+    want = torch.zeros(b, h + 2, w + 2, cs, dtype=torch.bfloat16, device=DEV)
+    want[:, 1:-1, 1:-1, :c] = y.view(b, h, w, c)
+    assert torch.equal(img.view(b, h + 2, w + 2, cs), want)
     assert not flat[: w + 3].any() and not flat[-(w + 3):].any()
     sums = ops.bn_bwd_stats(dy, None, x, mean, rstd, True, gamma, beta)
     dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
     dx, _ = ops.bn_bwd_apply(dy, None, x, mean, rstd, gamma, sums, rows, True, dg, db, False, beta=beta)
-    flat2, img2 = ops.halo_buffer(b, h, w, c, torch.bfloat16, DEV)
+    flat2, img2 = ops.halo_buffer(b, h, w, cs, torch.bfloat16, DEV)
     dg2, db2 = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
     ops.bn_bwd_apply(dy, None, x, mean, rstd, gamma, sums, rows, True, dg2, db2, False, beta=beta, halo=(img2, h, w))
-    want[:, 1:-1, 1:-1] = dx.view(b, h, w, c)
-    assert torch.equal(img2.view(b, h + 2, w + 2, c), want)
+    want[:, 1:-1, 1:-1, :c] = dx.view(b, h, w, c)
+    assert torch.equal(img2.view(b, h + 2, w + 2, cs), want)
     assert torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
