@@ -364,26 +364,31 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* x, const T*
         *(f32x4*)(partial + ((int64_t)blockIdx.y * 2 + 1) * C + c) = b;
     }
 }
-// out[0..C) = sum_b partial[b][0], out[C..2C) = sum_b partial[b][1] (fixed order: sixteen slices of the blocks per channel, then the slices);
-// shift != null: out[2C..3C) = shift values x[0][c] (forward statistics)
+// out[0..C) = sum_b partial[b][0], out[C..2C) = sum_b partial[b][1]: one block per four channels, thread t sums the row blocks t, t + 256, ...
+// (at most four loads each), then a fixed-order tree through LDS; shift != null: out[2C..3C) = shift values x[0][c] (forward statistics)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_collect_v_kernel(const float* partial, int nblocks, int C, const T* shift_row, float* out) {
-    __shared__ float sm[2][16][16];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;      // 16 channels per block, 16 slices of the row blocks per channel
-    const int c = blockIdx.x * 16 + cl;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int k = sl; k < nblocks; k += 16) {
-            a += partial[((int64_t)k * 2 + 0) * C + c];
-            b += partial[((int64_t)k * 2 + 1) * C + c];
-        }
-    sm[0][sl][cl] = a; sm[1][sl][cl] = b;
+    __shared__ f32x4 sm[2][256];
+    const int t = threadIdx.x, c = blockIdx.x * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int k = t; k < nblocks; k += 256) {
+        a += *(const f32x4*)(partial + ((int64_t)k * 2 + 0) * C + c);
+        b += *(const f32x4*)(partial + ((int64_t)k * 2 + 1) * C + c);
+    }
+    sm[0][t] = a; sm[1][t] = b;
     __syncthreads();
-    if (sl == 0 && c < C) {
-        for (int j = 1; j < 16; ++j) { a += sm[0][j][cl]; b += sm[1][j][cl]; }
-        out[c] = a;
-        out[C + c] = b;
-        if (shift_row) out[2 * C + c] = io<T>::ld(shift_row + c);
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { sm[0][t] += sm[0][t + o]; sm[1][t] += sm[1][t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        *(f32x4*)(out + c) = sm[0][0];
+        *(f32x4*)(out + C + c) = sm[1][0];
+        if (shift_row) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[2 * C + c + j] = io<T>::ld(shift_row + c + j);
+        }
     }
 }
 // halo_w != 0: the output goes to a zero-bordered NHWC image [B][halo_h + 2][halo_w + 2][CS] (row r = (b, y, x) -> pixel (y + 1, x + 1)),
@@ -584,7 +589,7 @@ extern "C" int sc_bn_stats(const void* x, int dtype, int64_t rows, int64_t c, fl
         hipLaunchKernelGGL((bn_partial_v4_kernel<T, 0>), dim3((unsigned)(c / (lpr * 4)), (unsigned)nbe), dim3(256), 0, st, (const T*)x, (const T*)nullptr, \
                            (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, (int)c, lpr, \
                            rpb, 0, (float*)ws);                                                                                            \
-        hipLaunchKernelGGL(bn_collect_v_kernel<T>, dim3((unsigned)sc_cdiv(c, 16)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const T*)x, stats); \
+        hipLaunchKernelGGL(bn_collect_v_kernel<T>, dim3((unsigned)(c / 4)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const T*)x, stats); \
     } while (0)
     const int lpr = vec_ok(8) ? bn_lpr(c) : 0;
     if (lpr) SC_DT(dtype, BSV(bf16_t), BSV(float));
@@ -637,7 +642,7 @@ extern "C" int sc_bn_bwd_stats(const void* dy, const void* y, const void* x, int
     const int lpr = vec_ok(32) ? bn_lpr(c) : 0;
     if (lpr) {
         SC_DT(dtype, BBV(bf16_t), BBV(float));
-        hipLaunchKernelGGL(bn_collect_v_kernel<float>, dim3((unsigned)sc_cdiv(c, 16)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const float*)nullptr, sums);
+        hipLaunchKernelGGL(bn_collect_v_kernel<float>, dim3((unsigned)(c / 4)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, (const float*)nullptr, sums);
     } else {
         SC_DT(dtype, BB(bf16_t), BB(float));
         hipLaunchKernelGGL(bn_bwd_collect_kernel, dim3((unsigned)sc_cdiv(c, 256)), dim3(256), 0, st, (const float*)ws, nbe, (int)c, sums);
