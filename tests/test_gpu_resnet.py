@@ -144,12 +144,16 @@ def _pair(name, precision, seed=3):
     return ref, model
 
 
-@pytest.mark.parametrize("name,precision", [("test-rn", "fp32"), ("test-rn64", "bf16"), ("test-rn32", "bf16")])
-def test_resnet_tower_forward_backward(ops, name, precision):
+@pytest.mark.parametrize("name,precision,im2col", [("test-rn", "fp32", False), ("test-rn64", "bf16", False), ("test-rn32", "bf16", False),
+                                                   ("test-rn32", "bf16", True)])
+def test_resnet_tower_forward_backward(ops, name, precision, im2col, monkeypatch):
     """The HIP ModifiedResNet tower against the oracle on identical weights: embeddings, every parameter gradient, the BatchNorm
     running statistics after the step; then evaluation mode (running statistics) against the oracle's eval forward."""
     from oracle.clip_model import synthetic_batch
+    if im2col:      # the patch-matrix form of the 3x3 convolutions (SC_RN_IM2COL=1, the A/B switch) instead of the implicit GEMMs
+        monkeypatch.setenv("SC_RN_IM2COL", "1")
     ref, model = _pair(name, precision)
+    assert any(model.rn.implicit(cv) for cv in model.rn.convs()) == (precision == "bf16" and not im2col)
     # the zero-initialised last BatchNorm weights would hide every main-path gradient: give them values
     sd = ref.state_dict()
     gen = torch.Generator().manual_seed(9)
