@@ -199,15 +199,12 @@ class ResNetVisual:
     def _bn_fwd(self, cv, z, relu, res=None, halo=None):
         rows, c = z.shape
         m = self.m
-        stats = ops.bn_stats(z)
-        world = D.world_size() if D.active() else 1
-        if world > 1:
-            stats = D.exchange_packets(stats).reshape(-1).contiguous()      # synchronised BatchNorm: the reference normalises over the whole batch
-        train = m.training
-        rm = m.buffers[cv.bn + ".running_mean"] if train else None
-        rv = m.buffers[cv.bn + ".running_var"] if train else None
-        if train:
-            mean, rstd = ops.bn_finish(stats, world, c, rows, rm, rv)
+        if m.training:
+            stats = ops.bn_stats(z)
+            world = D.world_size() if D.active() else 1
+            if world > 1:
+                stats = D.exchange_packets(stats).reshape(-1).contiguous()  # synchronised BatchNorm: the reference normalises over the whole batch
+            mean, rstd = ops.bn_finish(stats, world, c, rows, m.buffers[cv.bn + ".running_mean"], m.buffers[cv.bn + ".running_var"])
             m.buffers[cv.bn + ".num_batches_tracked"] += 1
         else:   # evaluation: the running statistics (sparsify_clip.py:540 model.eval())
             mean = m.buffers[cv.bn + ".running_mean"]
@@ -374,11 +371,10 @@ class ResNetVisual:
             da2 = self._conv_bwd(c3, dz3, rec["a2"], batch, ho, wo, acc)
             dy2 = ops.avgpool_bwd(da2, batch, h, w, c2.cout, stride) if stride > 1 else da2
             if self.implicit(c2):
-                flatd, imgd = ops.halo_buffer(batch, h, w, _pad64(c2.cout), m.dtype, dx.device)
+                _, imgd = ops.halo_buffer(batch, h, w, _pad64(c2.cout), m.dtype, dx.device)
                 self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc, halo=(imgd, h, w))      # dz2 into the bordered image
                 dy1 = ops.conv3x3_bf16(imgd, self.gw[c2.name][1], batch, h, w)
                 self._conv3x3_dw(c2, imgd, rec["y1_halo"], batch, h, w, acc)
-                del flatd
             else:
                 dz2, _ = self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc)
                 dy1 = self._conv_bwd(c2, dz2, rec["y1"], batch, h, w, acc)

@@ -18,6 +18,7 @@
 #   corun        tools/corun_bench.py: the persistent NT GEMM with 16 / 32 / 64 CUs taken by another stream, fixed lists vs tile tickets
 #                                                         -> gpurun_out/gemm_corun.txt
 #   ln           tools/ln_bench.py stand-alone LayerNorm forward / backward rates -> gpurun_out/layernorm_times.txt
+#   pipeline     tools/pipeline_bench.py: the input stage per phase (host assembly, H2D, loader alone, the step fed by the loader) -> gpurun_out/pipeline_bench.txt
 #   dp2          python bench.py --gpus 2 under SC_DIST_BACKEND=gloo on the one GPU (self-launch rehearsal) -> gpurun_out/dp2.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof $R/gpurun_out/pmc $R/gpurun_out/replay
@@ -87,6 +88,8 @@ for task in "$@"; do
       timeout -k 10 300 python tools/corun_bench.py > gpurun_out/gemm_corun.txt 2>&1; rc=$?; cat gpurun_out/gemm_corun.txt; [ $rc = 0 ] || exit $rc ;;
     ln)
       timeout -k 10 300 python tools/ln_bench.py > gpurun_out/layernorm_times.txt 2>&1; rc=$?; cat gpurun_out/layernorm_times.txt; [ $rc = 0 ] || exit $rc ;;
+    pipeline)
+      timeout -k 10 400 python tools/pipeline_bench.py > gpurun_out/pipeline_bench.txt 2>&1; rc=$?; cat gpurun_out/pipeline_bench.txt; [ $rc = 0 ] || exit $rc ;;
     attn)
       timeout -k 10 300 python tools/attn_bench.py > gpurun_out/attention_times.txt 2>&1; rc=$?; cat gpurun_out/attention_times.txt; [ $rc = 0 ] || exit $rc ;;
     *) echo "unknown task $task"; exit 2 ;;
