@@ -11,6 +11,8 @@
 #   pmc_gemm     SQ counter passes (MFMA busy ...) on the NT / TN kernels, three shapes each -> gpurun_out/pmc/gemm_counters.txt
 #   pmc_traffic  FETCH_SIZE / WRITE_SIZE passes over the replay launch set   -> gpurun_out/gemm_traffic.json
 #   pmc_loss     FETCH_SIZE / WRITE_SIZE + kernel times of the loss head at B = 8192 -> gpurun_out/pmc/loss_counters.txt
+#   pmc_bn       tools/bn_one.py: BatchNorm + implicit-convolution kernels at RN50's first-stage shape: times, FETCH_SIZE / WRITE_SIZE
+#                                                         -> gpurun_out/bn_conv_times.txt, pmc/bn_conv_counters.txt
 #   loss         tools/loss_bench.py                       -> gpurun_out/loss_head_times.txt
 #   attn / pmc_attn   tools/attn_bench.py timings / SQ counters of the attention kernels -> gpurun_out/attention_times.txt, pmc/attn_counters.txt
 #   configs      bench.py for BASELINE configs C2 / C3 / C5 (per-GPU shards), --precision fp32 and the YAMLs' own RN50 at batch 256
@@ -72,6 +74,12 @@ for task in "$@"; do
       PMC l_fetch FETCH_SIZE -- $R/tools/loss_one.py || exit 1
       PMC l_write WRITE_SIZE GRBM_GUI_ACTIVE -- $R/tools/loss_one.py || exit 1
       python3 tools/pmc_table.py "" $R/gpurun_out/pmc/l_fetch $R/gpurun_out/pmc/l_write > $R/gpurun_out/pmc/loss_counters.txt; cat $R/gpurun_out/pmc/loss_counters.txt ;;
+    pmc_bn)
+      timeout -k 10 300 python tools/bn_one.py > gpurun_out/bn_conv_times.txt 2>&1 || { cat gpurun_out/bn_conv_times.txt; exit 1; }
+      cat gpurun_out/bn_conv_times.txt
+      PMC b_fetch FETCH_SIZE -- $R/tools/bn_one.py || exit 1
+      PMC b_write WRITE_SIZE GRBM_GUI_ACTIVE -- $R/tools/bn_one.py || exit 1
+      python3 tools/pmc_table.py "" $R/gpurun_out/pmc/b_fetch $R/gpurun_out/pmc/b_write | grep -E "bn_|gemm_bf16|splitk" > $R/gpurun_out/pmc/bn_conv_counters.txt; cat $R/gpurun_out/pmc/bn_conv_counters.txt ;;
     pmc_attn)
       PMC a_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $R/tools/attn_bench.py || exit 1
       PMC a_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES -- $R/tools/attn_bench.py || exit 1
