@@ -60,6 +60,7 @@ class ResNetVisual:
         self.cfeat = inplanes                      # 32 * width
         self.hw = (self.image_size // 32) ** 2
         self.saved = None
+        self._halos = {}
         self.gw = {}                               # conv name -> (GEMM-layout weight [Cout, kpad], its transpose [kpad, Cout]) in the compute dtype
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -251,6 +252,20 @@ class ResNetVisual:
             return ops.col2im3x3(dcols, batch, h, w, cv.cin, cv.stride, kpad)
         return dcols
 
+    def _halo(self, tag, batch, h, w, c, device):
+        """The bordered image (ops.halo_buffer) a BatchNorm apply writes for an implicit convolution, kept across steps: the kernels
+        only ever write interior pixels and the first channels, so border, slack rows and padding channels stay zero and the
+        110 MB memset per layer and step is paid once.  tag: the producing layer (its image lives until that layer's backward) or
+        "grad<channels>" (an output-gradient image is consumed by the two launches right behind it on the same stream, so one per shape
+        and real channel count - a 32-channel gradient must not inherit the upper channels of a 64-channel one)."""
+        key = (tag, batch, h, w, c, self.m.dtype, str(device))
+        buf = self._halos.get(key)
+        if buf is None:
+            if len(self._halos) > 256:      # a stream of different batch sizes: start over rather than grow
+                self._halos.clear()
+            buf = self._halos[key] = ops.halo_buffer(batch, h, w, c, self.m.dtype, device)
+        return buf
+
     def _conv3x3_dw(self, cv, dz_img, x_flat, batch, h, w, acc):
         """Weight gradient of an implicit convolution, one TN GEMM whose B operand is the bordered input read through the nine tap shifts
         (sc_conv3x3_dw_bf16; the zero border of dz makes the border rows contribute nothing)."""
@@ -277,7 +292,7 @@ class ResNetVisual:
             else:
                 z, ho, wo = self._conv_fwd(cv, x, batch, h, w, images=images if i == 0 else None)
             if i + 1 < len(self.stem) and self.implicit(self.stem[i + 1]):
-                out_halo = ops.halo_buffer(batch, ho, wo, _pad64(cv.cout), m.dtype, z.device)
+                out_halo = self._halo(cv.name, batch, ho, wo, _pad64(cv.cout), z.device)
                 y, (_, mean, rstd) = None, self._bn_fwd(cv, z, True, halo=(out_halo[1], ho, wo))
             else:
                 out_halo = None
@@ -291,7 +306,7 @@ class ResNetVisual:
             rec = {"x": x, "h": h, "w": w}
             z1, _, _ = self._conv_fwd(c1, x, batch, h, w)
             if self.implicit(c2):      # bn1 writes straight into the bordered image conv2 reads; no compact y1, no patch matrix
-                flat1, img1 = ops.halo_buffer(batch, h, w, _pad64(c1.cout), m.dtype, z1.device)
+                flat1, img1 = self._halo(c1.name, batch, h, w, _pad64(c1.cout), z1.device)
                 _, m1, r1 = self._bn_fwd(c1, z1, True, halo=(img1, h, w))
                 y1 = None
                 rec["y1_halo"] = flat1
@@ -371,7 +386,7 @@ class ResNetVisual:
             da2 = self._conv_bwd(c3, dz3, rec["a2"], batch, ho, wo, acc)
             dy2 = ops.avgpool_bwd(da2, batch, h, w, c2.cout, stride) if stride > 1 else da2
             if self.implicit(c2):
-                _, imgd = ops.halo_buffer(batch, h, w, _pad64(c2.cout), m.dtype, dx.device)
+                _, imgd = self._halo(f"grad{c2.cout}", batch, h, w, _pad64(c2.cout), dx.device)
                 self._bn_bwd(c2, dy2, rec["y2"], rec["z2"], rec["m2"], rec["r2"], True, acc, halo=(imgd, h, w))      # dz2 into the bordered image
                 dy1 = ops.conv3x3_bf16(imgd, self.gw[c2.name][1], batch, h, w)
                 self._conv3x3_dw(c2, imgd, rec["y1_halo"], batch, h, w, acc)
@@ -395,7 +410,7 @@ class ResNetVisual:
             cv = self.stem[i]
             x_in, x_halo, z, y, mean, rstd, hi, wi = S["stem"][i]
             if self.implicit(cv):
-                _, imgd = ops.halo_buffer(batch, hi, wi, _pad64(cv.cout), m.dtype, dx.device)
+                _, imgd = self._halo(f"grad{cv.cout}", batch, hi, wi, _pad64(cv.cout), dx.device)
                 self._bn_bwd(cv, dx, y, z, mean, rstd, True, acc, halo=(imgd, hi, wi))
                 dx = ops.conv3x3_bf16(imgd, self.gw[cv.name][1], batch, hi, wi)
                 self._conv3x3_dw(cv, imgd, x_halo[0], batch, hi, wi, acc)
