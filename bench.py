@@ -60,6 +60,8 @@ def parse():
     p.add_argument("--text-trim", type=int, default=1, help="N = 1 only: after the timed region, time the step again with `text_trim: True` (the "
                    "text tower runs over the batch's longest caption instead of all 77 positions; same results) and report it as 'with_text_trim'; "
                    "the headline value always computes every position, as the reference does")
+    p.add_argument("--global-batch-one-gpu", type=int, default=8192, help="N = 1 only: after the timed region, time the metric's global batch as ONE step on "
+                   "this GPU through Trainer.step_cached (micro-batches of --local-batch); 0 = off")
     p.add_argument("--simulate-dp", type=int, default=8, help="N = 1 only: after the timed region, time the step again with the loss head fed a "
                    "global batch of simulate_dp x local_batch rows (filler rows for the absent ranks) = the per-GPU work of that DP job; 1 = off")
     return p.parse_args()
@@ -254,7 +256,8 @@ def main():
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, local batch {args.local_batch}/GPU, "
                                   f"global batch {global_batch}, AdamW, random-init weights; weak scaling: N = 8 is the metric's global batch 8192 "
-                                  f"(8192 pairs on ONE GPU need ~280 GB of saved activations + weights: does not fit 288 GB, see dp_rank_equivalent)",
+                                  f"(8192 pairs on ONE GPU need ~280 GB of saved activations + weights: does not fit 288 GB; see dp_rank_equivalent for one rank's work "
+                                  f"of that job and global_batch_one_gpu for the whole 8192-pair step on this GPU by micro-batches)",
                       "global_batch": global_batch, "local_batch": args.local_batch, "parallelism": f"dp{world}"},
            "last_loss": last_loss,
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
@@ -274,6 +277,24 @@ def main():
                                      "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
                                      "note": "compute of one rank of the DP job: the loss head takes this rank's 1/world of the rows against the whole gathered batch "
                                              "(step_loss_rows); the statistics exchange and the other collectives are not simulated"}
+    if world == 1 and args.global_batch_one_gpu > args.local_batch and trainer.model.rn is None:
+        # the metric's own global batch on ONE GPU: Trainer.step_cached = towers over micro-batches, loss head once over all pairs, forward again +
+        # backward per micro-batch (the saved activations of 8192 pairs, ~280 GB, do not fit; 4/3 of the encoder work instead)
+        gb = args.global_batch_one_gpu - args.global_batch_one_gpu % args.local_batch
+        big_tokens = synthetic_batch(4242, gb, 8, c["ctx"], c["vocab"])[1].to(device)
+        big_images = torch.randn(gb, 3, c["image_size"], c["image_size"], device=device, generator=torch.Generator(device=device).manual_seed(4242))
+        trainer.step_cached(big_images, big_tokens, args.local_batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            trainer.step_cached(big_images, big_tokens, args.local_batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 2
+        del big_images, big_tokens
+        out["global_batch_one_gpu"] = {"global_batch": gb, "micro_batch": args.local_batch, "ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(gb / dt, 1),
+                                       "note": "the whole global-batch step on one GPU (Trainer.step_cached: embeddings of all micro-batches, ONE loss head over "
+                                               "every pair, then forward again + backward per micro-batch, one optimiser step); equal to step() up to fp32 summation "
+                                               "order (tests/test_gpu_model.py::test_step_cached_equals_step); not the headline value"}
     if world == 1 and args.text_trim:
         # opt-in: text tower over the longest caption of the batch only (padding behind EOT cannot influence the result under the causal mask)
         from sparsify_clip_amd.data import caption_length

@@ -145,6 +145,79 @@ class Trainer:
             self.flush_logs()
         return res.loss
 
+    def step_cached(self, images, captions, micro_batch):
+        """The SAME step for a batch whose saved activations do not fit the GPU (global batch 8192 of ViT-B/32 is ~280 GB of them):
+        (1) both towers forward over micro-batches, keeping only the [B, E] embeddings; (2) the loss head ONCE over the whole batch -
+        the O(B^2) terms see every pair, which plain gradient accumulation over micro-batches would not give; (3) per micro-batch the
+        forward again (its activations saved this time) and the backward with its rows of dL/d(embedding), parameter gradients
+        accumulating in the flat buffer; (4) one optimiser step.  The result equals step() on the whole batch up to fp32 summation order
+        (tests/test_gpu_model.py::test_step_cached_equals_step) at 4/3 of its encoder work.  Single process, LayerNorm models only:
+        BatchNorm statistics of a micro-batch are not the batch's."""
+        cfg, m = self.config, self.model
+        if m.rn is not None:
+            raise ScError("step_cached: the ModifiedResNet tower normalises over the batch; micro-batches would change the result")
+        if D.active() and D.world_size() > 1:
+            raise ScError("step_cached is the one-GPU form of a global-batch step; with several ranks use step() (the batch is sharded)")
+        batch = images.shape[0]
+        if micro_batch <= 0 or batch % micro_batch:
+            raise ScError(f"step_cached: batch {batch} is not a multiple of the micro-batch {micro_batch}")
+        self.current_batch += 1
+        tokens = captions if isinstance(captions, torch.Tensor) else self.tokenizer(captions)
+        tokens = tokens.to(self.device)
+        main = torch.cuda.current_stream()
+        if self.text_stream is None:
+            self.text_stream = torch.cuda.Stream(device=self.device)
+        parts = [slice(k, k + micro_batch) for k in range(0, batch, micro_batch)]
+
+        def towers(sl):
+            self.text_stream.wait_stream(main)
+            with torch.cuda.stream(self.text_stream):
+                te = m.text_forward(tokens[sl])
+            ie = m.image_forward(images[sl])
+            main.wait_stream(self.text_stream)
+            return ie, te
+
+        e = m.cfg["embed_dim"]
+        img_e = torch.empty(batch, e, dtype=torch.float32, device=self.device)
+        txt_e = torch.empty(batch, e, dtype=torch.float32, device=self.device)
+        for sl in parts:
+            ie, te = towers(sl)
+            img_e[sl].copy_(ie)
+            txt_e[sl].copy_(te)
+        img_n, inv_i = ops.l2norm_fwd(img_e, 0.0)
+        txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0)
+        temp = float(self.temperature.detach()) if self.learnable_t else float(self.temperature)
+        res = step_loss(cfg, img_n, txt_n, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)
+        if res.beta is not None:
+            self.beta = res.beta
+        if res.alpha is not None:
+            self.alpha = res.alpha
+        row = {"learning_rate": self.scheduler.get_last_lr()[0]}
+        if self.learnable_t:
+            row["constrantive_temperature_learnable"] = temp
+        else:
+            row.update(beta=self.beta, alpha=self.alpha)
+        self.pending_logs.append((res.loss, row))
+        self.optimizer.zero_grad()
+        d_img_e = ops.l2norm_bwd(img_n, inv_i, res.d_img)
+        d_txt_e = ops.l2norm_bwd(txt_n, inv_t, res.d_txt)
+        for sl in parts:
+            towers(sl)                                   # the activations of this micro-batch, saved for its backward
+            di, dt = d_img_e[sl].contiguous(), d_txt_e[sl].contiguous()
+            self.text_stream.wait_stream(main)
+            with torch.cuda.stream(self.text_stream):
+                m.text_backward(dt)                      # the first micro-batch overwrites the gradient buffer, the others accumulate
+            m.image_backward(di)
+            main.wait_stream(self.text_stream)
+        if self.learnable_t and res.d_temp is not None:
+            self.temperature.grad = res.d_temp.detach().cpu().reshape(())
+        self.sync.wait_all()
+        self.optimizer.step()
+        self.scheduler.step()
+        if len(self.pending_logs) >= cfg.get("log_every", 10):
+            self.flush_logs()
+        return res.loss
+
     # ---- optional full-state sidecar (the reference resumes WEIGHTS only, :719-724; SURVEY 5.4 asks for an opt-in sidecar)
     def full_state(self) -> dict:
         """Everything besides the weights that a bit-exact continuation needs, as a flat {str: Tensor} (weights_only-loadable)."""

@@ -462,3 +462,39 @@ def test_text_trim_equivalence(pkg, name, precision, batch):
             losses[trim] = [tr.step(images, tokens).item() for _ in range(3)]
         for a, b in zip(losses[False], losses[True]):
             assert abs(a - b) <= (2e-5 if precision == "fp32" else 2e-2) * abs(a), (losses,)
+
+
+@pytest.mark.parametrize("experiment,precision", [("experiment_6-", "fp32"), ("experiment_10-", "fp32"), ("experiment_6-", "bf16")])
+def test_step_cached_equals_step(pkg, experiment, precision):
+    """Trainer.step_cached (towers over micro-batches keeping only the embeddings, the loss head ONCE over the whole batch, then per
+    micro-batch forward + backward with its rows of the embedding gradient, gradients accumulating) is the same step as Trainer.step on
+    the whole batch: losses and parameters after three optimiser steps agree to fp32 summation order (fp32 path) / bf16 level.  This is
+    how the metric's global batch 8192 runs on ONE GPU although its saved activations (~280 GB) do not fit."""
+    from conftest import load_json
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.data import synthetic_batch
+    from sparsify_clip_amd.train import Trainer
+    from sparsify_clip_amd._lib import ScError
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if experiment in k][0]]
+    name, batch = "test-small", 32
+    runs = {}
+    for mode in ("whole", "cached"):
+        cfg = finalize_config(raw, 0, {"model": name, "batch_size": batch, "precision": precision})
+        tr = Trainer(cfg, DEV, 10, model=pkg.ClipModel(name, device=DEV, precision=precision, seed=5))
+        tr.epoch = 1
+        c = tr.model.cfg
+        losses = []
+        for k in range(3):
+            images, tokens = [t.to(DEV) for t in synthetic_batch(90 + k, batch, c["image_size"], c["ctx"], c["vocab"])]
+            loss = tr.step(images, tokens) if mode == "whole" else tr.step_cached(images, tokens, 8)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        runs[mode] = (losses, tr.model.flat.clone())
+        if mode == "cached":
+            with pytest.raises(ScError):
+                tr.step_cached(images, tokens, 5)      # 32 is not a multiple of 5
+    tol_l, tol_p = (2e-6, 2e-5) if precision == "fp32" else (2e-2, 5e-2)
+    for a, b in zip(*[r[0] for r in runs.values()]):
+        assert abs(a - b) <= tol_l * abs(a), runs
+    assert rel_err(runs["cached"][1], runs["whole"][1]) < tol_p

@@ -46,7 +46,7 @@ for task in "$@"; do
       echo "dp2 rc=$rc"; tail -3 gpurun_out/dp2.err; cat gpurun_out/dp2.json
       [ $rc = 0 ] || exit $rc ;;
     prof)
-      (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --simulate-dp 1 ${BENCH_ARGS} > $R/gpurun_out/rocprof.log 2>&1); rc=$?
+      (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --simulate-dp 1 --global-batch-one-gpu 0 ${BENCH_ARGS} > $R/gpurun_out/rocprof.log 2>&1); rc=$?
       echo "rocprof rc=$rc"
       find $R/gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
       python3 tools/kernel_stats.py $R/gpurun_out/prof/bench_kernel_stats.csv 24
@@ -89,7 +89,7 @@ for task in "$@"; do
                   "c5 --experiment experiment_10 --model ViT-L-14 --local-batch 512" "fp32 --precision fp32 --local-batch 256" \
                   "rn50 --model RN50 --local-batch 256"; do
         set -- $spec; name=$1; shift
-        timeout -k 10 500 python bench.py --steps 4 --warmup 2 --cpu-baseline 0 --simulate-dp 1 "$@" > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; rc=$?
+        timeout -k 10 500 python bench.py --steps 4 --warmup 2 --cpu-baseline 0 --simulate-dp 1 --global-batch-one-gpu 0 "$@" > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; rc=$?
         echo "$name rc=$rc"; cut -c1-330 gpurun_out/bench_$name.json; echo; [ $rc = 0 ] || exit $rc
       done ;;
     corun)
