@@ -35,6 +35,8 @@ def parse_args(argv=None):
     p.add_argument("--eval-batch-size", type=int, default=None)
     p.add_argument("--steps-per-epoch", type=int, default=None)
     p.add_argument("--precision", choices=["bf16", "fp32"], default=None)
+    p.add_argument("--micro-batch", type=int, default=None, help="run every step through Trainer.step_cached with this micro-batch: the same step "
+                   "(loss over the whole batch) for batches whose activations do not fit the GPU; ViT models, one process")
     return p.parse_args(argv)
 
 
@@ -44,7 +46,7 @@ def run(argv=None):
     device_id = local_rank if world > 1 else args.device
     overrides = {"model": args.model, "batch_size": args.batch_size, "epochs": args.epochs, "num_train_samples": args.num_train_samples,
                  "num_test_samples": args.num_test_samples, "eval_batch_size": args.eval_batch_size, "steps_per_epoch": args.steps_per_epoch,
-                 "precision": args.precision}
+                 "precision": args.precision, "micro_batch": args.micro_batch}
     results = {}
     for path in config_files(args.config):
         config = load_config(path, device_id, overrides)

@@ -22,7 +22,8 @@ REQUIRED_KEYS = ["project_name", "run_name", "seed", "learning_rate", "batch_siz
 # input_pipeline: "resident" = pre-normalised fp32 batches already in HBM (the benchmark's contract), "device" = uint8 pixels through
 # the host assembly + H2D copy + device augmentation of input_pipeline.py (always used when synthetic is False)
 EXTRA_DEFAULTS = {"precision": None, "synthetic": True, "eval_batch_size": None, "dp": 1, "log_every": 10, "steps_per_epoch": None,
-                  "input_pipeline": "resident", "full_state_checkpoint": False, "text_trim": False, "shard_loss_head": True}
+                  "input_pipeline": "resident", "full_state_checkpoint": False, "text_trim": False, "shard_loss_head": True,
+                  "micro_batch": 0}      # > 0: Trainer.step_cached (whole-batch loss, towers by micro-batches) instead of Trainer.step
 
 
 def load_config(path: str, device_id: int = 0, overrides: dict | None = None):

@@ -372,8 +372,12 @@ def train_model(config, train_loader, test_loader, device, logger=None):
     evaluate_model(model, test_loader, device, logger=logger)   # :740
     for epoch in range(start_epoch, start_epoch + config["epochs"]):
         trainer.epoch = epoch
+        micro = int(config.get("micro_batch") or 0)
         for images, captions in train_loader:
-            trainer.step(images, captions)
+            if 0 < micro < images.shape[0]:
+                trainer.step_cached(images, captions, micro)
+            else:
+                trainer.step(images, captions)
         trainer.flush_logs()
         evaluate_model(model, test_loader, device, logger=logger)   # :980
         if (epoch + 1) % config["save_checkpoint_every_n_epochs"] == 0 and D.get_rank() == 0:   # :982-984

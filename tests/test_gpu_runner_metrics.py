@@ -155,6 +155,12 @@ def test_runner_end_to_end(gpu, tmp_path, monkeypatch):
     m.load_state_dict(torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True))
     sd = torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True)
     assert torch.equal(m.param("visual.proj").cpu(), sd["module.visual.proj"])
+    # --micro-batch: every step through Trainer.step_cached (whole-batch loss, towers by micro-batches of 4): the same training run
+    final = sd
+    sparsify_clip.run(["--config", str(path), "--device", "0", "--model", "tiny", "--steps-per-epoch", "3", "--precision", "fp32", "--micro-batch", "4"])
+    sd = torch.load(tmp_path / "models" / "runner_test.pt", map_location="cpu", weights_only=True)
+    for k in ("module.visual.proj", "module.transformer.resblocks.0.mlp.c_fc.weight", "module.token_embedding.weight"):
+        assert torch.allclose(sd[k], final[k], rtol=1e-4, atol=2e-6), k
     # the same runner on the ModifiedResNet geometry (what the YAML's literal "RN50" selects at real size): the evaluation runs on the
     # BatchNorm running statistics and the checkpoint carries them under open_clip's keys
     out = sparsify_clip.run(["--config", str(path), "--device", "0", "--model", "test-rn", "--steps-per-epoch", "2", "--precision", "fp32", "--epochs", "1"])
