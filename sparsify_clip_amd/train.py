@@ -150,8 +150,9 @@ class Trainer:
         (1) both towers forward over micro-batches, keeping only the [B, E] embeddings; (2) the loss head ONCE over the whole batch -
         the O(B^2) terms see every pair, which plain gradient accumulation over micro-batches would not give; (3) per micro-batch the
         forward again (its activations saved this time) and the backward with its rows of dL/d(embedding), parameter gradients
-        accumulating in the flat buffer; (4) one optimiser step.  The result equals step() on the whole batch up to fp32 summation order
-        (tests/test_gpu_model.py::test_step_cached_equals_step) at 4/3 of its encoder work.  Single process, LayerNorm models only:
+        accumulating in the flat buffer (the last micro-batch goes first: its activations are still there); (4) one optimiser step.  The
+        result equals step() on the whole batch up to fp32 summation order (tests/test_gpu_model.py::test_step_cached_equals_step) at
+        about 4/3 of its encoder work.  Single process, LayerNorm models only:
         BatchNorm statistics of a micro-batch are not the batch's."""
         cfg, m = self.config, self.model
         if m.rn is not None:
@@ -201,8 +202,9 @@ class Trainer:
         self.optimizer.zero_grad()
         d_img_e = ops.l2norm_bwd(img_n, inv_i, res.d_img)
         d_txt_e = ops.l2norm_bwd(txt_n, inv_t, res.d_txt)
-        for sl in parts:
-            towers(sl)                                   # the activations of this micro-batch, saved for its backward
+        for k, sl in enumerate(reversed(parts)):         # last micro-batch first: its activations are still in the towers' buffers
+            if k > 0:
+                towers(sl)                               # the activations of this micro-batch, saved for its backward
             di, dt = d_img_e[sl].contiguous(), d_txt_e[sl].contiguous()
             self.text_stream.wait_stream(main)
             with torch.cuda.stream(self.text_stream):
