@@ -345,3 +345,27 @@ def test_conv3x3_implicit_weight_gradient(ops, b, h, w, cin, cout):
     acc = torch.ones(cout, 9 * cin, device=DEV)
     ops.conv3x3_dw_bf16(dimg, xflat, b, h, w, out=acc, beta=1.0)
     assert rel(acc.view(cout, 3, 3, cin).permute(0, 3, 1, 2), wt.grad + 1) < 1e-5
+
+
+def test_conv_entry_points_refuse_bad_shapes(ops):
+    """The implicit-convolution entry points and their host wrappers fail loudly (status + message, no launch) on operands that do not match
+    the kernels' assumptions: a channel count that is not 64 * 2^j, a bordered image of the wrong size, a weight matrix of the wrong width, a
+    BatchNorm image narrower than the activation, a weight-gradient input without its slack rows."""
+    from sparsify_clip_amd._lib import ScError
+    b, h, w = 2, 6, 6
+    with pytest.raises(ScError, match="64 times a power of two"):
+        _, img = ops.halo_buffer(b, h, w, 192, torch.bfloat16, DEV)
+        ops.conv3x3_bf16(img, torch.zeros(64, 9 * 192, dtype=torch.bfloat16, device=DEV), b, h, w)
+    flat, img = ops.halo_buffer(b, h, w, 64, torch.bfloat16, DEV)
+    wt = torch.zeros(64, 9 * 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ScError, match="a_halo has"):
+        ops.conv3x3_bf16(img, wt, b, h + 1, w)
+    with pytest.raises(ScError, match="w_taps is"):
+        ops.conv3x3_bf16(img, wt[:, :-64].contiguous(), b, h, w)
+    with pytest.raises(ScError, match="x_flat"):
+        ops.conv3x3_dw_bf16(img, img, b, h, w)              # the image view instead of the flat buffer: no slack rows
+    x = torch.zeros(b * h * w, 128, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
+    with pytest.raises(ScError, match="bordered image"):
+        ops.bn_apply(x, mean, rstd, rstd, mean, True, halo=(img, h, w))      # a 128-channel activation into a 64-channel image
+    assert ops.conv3x3_dw_bf16(img, flat, b, h, w).abs().max().item() == 0.0
