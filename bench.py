@@ -60,6 +60,9 @@ def parse():
     p.add_argument("--text-trim", type=int, default=1, help="N = 1 only: after the timed region, time the step again with `text_trim: True` (the "
                    "text tower runs over the batch's longest caption instead of all 77 positions; same results) and report it as 'with_text_trim'; "
                    "the headline value always computes every position, as the reference does")
+    p.add_argument("--global-batch", type=int, default=0, help="STRONG scaling instead of the default weak scaling: this global batch is split over "
+                   "the N ranks (SURVEY 8d: 8192 at 1 / 2 / 4 / 8 GPUs); a rank whose share exceeds --local-batch runs it by micro-batches of "
+                   "--local-batch through Trainer.step_cached (same step, ~4/3 of the encoder work).  0 = weak scaling (--local-batch pairs per GPU)")
     p.add_argument("--global-batch-one-gpu", type=int, default=8192, help="N = 1 only: after the timed region, time the metric's global batch as ONE step on "
                    "this GPU through Trainer.step_cached (micro-batches of --local-batch); 0 = off")
     p.add_argument("--simulate-dp", type=int, default=8, help="N = 1 only: after the timed region, time the step again with the loss head fed a "
@@ -221,13 +224,26 @@ def main():
     torch.cuda.set_device(device)
     from sparsify_clip_amd.data import synthetic_batch
     from sparsify_clip_amd.train import Trainer
-    global_batch = args.local_batch * world
+    strong = args.global_batch > 0
+    if strong and args.global_batch % (world * args.local_batch) and args.global_batch % world:
+        raise SystemExit(f"bench.py: --global-batch {args.global_batch} is not divisible by {world} ranks")
+    rank_batch = args.global_batch // world if strong else args.local_batch      # pairs per rank and step
+    global_batch = rank_batch * world
     key, cfg = reference_config(args.experiment, args.model, global_batch, args.precision)
     progress(f"rank {rank}/{world}: building {args.model} ({args.precision}) and synthetic batches")
     trainer = Trainer(cfg, device, steps_per_epoch=1000)
     trainer.epoch = max(1, cfg["only_lunif_epochs"])       # main phase: the full loss stack, not the warm-up branch
     c = trainer.model.cfg
-    batches = [tuple(t.to(device) for t in synthetic_batch(42 + rank + 100 * k, args.local_batch, c["image_size"], c["ctx"], c["vocab"])) for k in range(2)]
+    if strong:      # big shards: token rows from the seeded generator, pixels drawn on the device (i.i.d. N(0, 1) as SURVEY 8d, another stream)
+        gen = torch.Generator(device=device).manual_seed(42 + rank)
+        batches = [(torch.randn(rank_batch, 3, c["image_size"], c["image_size"], device=device, generator=gen),
+                    synthetic_batch(42 + rank + 100 * k, rank_batch, 8, c["ctx"], c["vocab"])[1].to(device)) for k in range(2)]
+    else:
+        batches = [tuple(t.to(device) for t in synthetic_batch(42 + rank + 100 * k, args.local_batch, c["image_size"], c["ctx"], c["vocab"])) for k in range(2)]
+    cached = strong and rank_batch > args.local_batch and rank_batch % args.local_batch == 0
+
+    def run_step(b):
+        return trainer.step_cached(*b, args.local_batch) if cached else trainer.step(*b)
 
     def barrier():
         if world > 1:
@@ -235,13 +251,13 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        trainer.step(*batches[i % 2])
+        run_step(batches[i % 2])
         torch.cuda.synchronize()
         progress(f"warm-up step {i + 1}/{args.warmup} done")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = trainer.step(*batches[i % 2])
+        loss = run_step(batches[i % 2])
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -252,16 +268,18 @@ def main():
     progress(f"timed {args.steps} steps in {elapsed:.3f}s")
     pairs_per_s = global_batch * args.steps / elapsed
     out = {"metric": "image-text pairs/sec", "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-           "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, local batch {args.local_batch}/GPU, "
-                                  f"global batch {global_batch}, AdamW, random-init weights; weak scaling: N = 8 is the metric's global batch 8192 "
+           "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, local batch {rank_batch}/GPU"
+                                  + (f" by micro-batches of {args.local_batch} (Trainer.step_cached)" if cached else "") +
+                                  f", global batch {global_batch}, AdamW, random-init weights; "
+                                  + ("strong scaling: the global batch is fixed over N " if strong else "weak scaling: N = 8 is the metric's global batch 8192 ") +
                                   f"(8192 pairs on ONE GPU need ~280 GB of saved activations + weights: does not fit 288 GB; see dp_rank_equivalent for one rank's work "
                                   f"of that job and global_batch_one_gpu for the whole 8192-pair step on this GPU by micro-batches)",
-                      "global_batch": global_batch, "local_batch": args.local_batch, "parallelism": f"dp{world}"},
+                      "global_batch": global_batch, "local_batch": rank_batch, "parallelism": f"dp{world}"},
            "last_loss": last_loss,
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
-    if world == 1 and args.simulate_dp > 1:
+    if world == 1 and not strong and args.simulate_dp > 1:
         # what ONE rank of a simulate_dp-GPU job computes per step (its row block of the global-batch loss head included; no collective)
         D.simulate_world(args.simulate_dp)
         trainer.step(*batches[0])
@@ -277,7 +295,7 @@ def main():
                                      "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
                                      "note": "compute of one rank of the DP job: the loss head takes this rank's 1/world of the rows against the whole gathered batch "
                                              "(step_loss_rows); the statistics exchange and the other collectives are not simulated"}
-    if world == 1 and args.global_batch_one_gpu > args.local_batch and trainer.model.rn is None:
+    if world == 1 and not strong and args.global_batch_one_gpu > args.local_batch and trainer.model.rn is None:
         # the metric's own global batch on ONE GPU: Trainer.step_cached = towers over micro-batches, loss head once over all pairs, forward again +
         # backward per micro-batch (the saved activations of 8192 pairs, ~280 GB, do not fit; 4/3 of the encoder work instead)
         gb = args.global_batch_one_gpu - args.global_batch_one_gpu % args.local_batch
@@ -295,7 +313,7 @@ def main():
                                        "note": "the whole global-batch step on one GPU (Trainer.step_cached: embeddings of all micro-batches, ONE loss head over "
                                                "every pair, then forward again + backward per micro-batch, one optimiser step); equal to step() up to fp32 summation "
                                                "order (tests/test_gpu_model.py::test_step_cached_equals_step); not the headline value"}
-    if world == 1 and args.text_trim:
+    if world == 1 and not strong and args.text_trim:
         # opt-in: text tower over the longest caption of the batch only (padding behind EOT cannot influence the result under the causal mask)
         from sparsify_clip_amd.data import caption_length
         lens = [caption_length(b[1]) for b in batches]
@@ -314,7 +332,7 @@ def main():
                                  "note": "config key text_trim: the text tower runs over the batch's longest caption (synthetic captions: 5-30 words + SOT/EOT, "
                                          "SURVEY 8d) rounded up to a multiple of 8 instead of all 77 positions; embeddings and gradients are the same "
                                          "(tests/test_gpu_model.py::test_text_trim_equivalence); not the headline value"}
-    if world == 1 and args.input_pipeline:
+    if world == 1 and not strong and args.input_pipeline:
         # the same step fed by the real input path: uint8 pixels -> pinned staging -> H2D on a side stream -> device crop/resize/flip/normalise
         from sparsify_clip_amd.input_pipeline import DeviceAugLoader, SyntheticCocoDataset
         nsteps = min(args.steps, 8)

@@ -152,13 +152,12 @@ class Trainer:
         forward again (its activations saved this time) and the backward with its rows of dL/d(embedding), parameter gradients
         accumulating in the flat buffer (the last micro-batch goes first: its activations are still there); (4) one optimiser step.  The
         result equals step() on the whole batch up to fp32 summation order (tests/test_gpu_model.py::test_step_cached_equals_step) at
-        about 4/3 of its encoder work.  Single process, LayerNorm models only:
-        BatchNorm statistics of a micro-batch are not the batch's."""
+        about 4/3 of its encoder work.  Under data parallelism `images` / `captions` are the rank's shard: embeddings gathered, loss head by rows,
+        each gradient bucket all-reduced once (behind the last micro-batch's backward).  LayerNorm models only: BatchNorm statistics of a
+        micro-batch are not the batch's."""
         cfg, m = self.config, self.model
         if m.rn is not None:
             raise ScError("step_cached: the ModifiedResNet tower normalises over the batch; micro-batches would change the result")
-        if D.active() and D.world_size() > 1:
-            raise ScError("step_cached is the one-GPU form of a global-batch step; with several ranks use step() (the batch is sharded)")
         batch = images.shape[0]
         if micro_batch <= 0 or batch % micro_batch:
             raise ScError(f"step_cached: batch {batch} is not a multiple of the micro-batch {micro_batch}")
@@ -185,10 +184,23 @@ class Trainer:
             ie, te = towers(sl)
             img_e[sl].copy_(ie)
             txt_e[sl].copy_(te)
-        img_n, inv_i = ops.l2norm_fwd(img_e, 0.0)
-        txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0)
+        # from here to the embedding gradients: exactly step() - under data parallelism `images` is this rank's shard, the embeddings of
+        # all ranks are gathered and the loss head (by rows, or replicated) sees the global batch
+        send = D.gather_send_buffer(batch, e, img_e.device)[0] if D.active() else (None, None)
+        img_n, inv_i = ops.l2norm_fwd(img_e, 0.0, out=send[0])
+        txt_n, inv_t = ops.l2norm_fwd(txt_e, 0.0, out=send[1])
+        img_all, txt_all = D.all_gather_embeddings(img_n, txt_n)
         temp = float(self.temperature.detach()) if self.learnable_t else float(self.temperature)
-        res = step_loss(cfg, img_n, txt_n, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)
+        world, rank = D.sharding()
+        rows = img_all.shape[0] // world
+        sharded = world > 1 and cfg.get("shard_loss_head", True) and ops.loss_rows_supported(img_all.shape[0], img_all.shape[1], rank * rows, rows)
+        if sharded:
+            res = step_loss_rows(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, rank * rows, rows, D.exchange_packets,
+                                 want_dtemp=self.learnable_t)
+            if res.d_temp is not None:
+                D.all_reduce_sum_(res.d_temp)
+        else:
+            res = step_loss(cfg, img_all, txt_all, temp, self.epoch, self.current_batch, self.t_total, want_dtemp=self.learnable_t)
         if res.beta is not None:
             self.beta = res.beta
         if res.alpha is not None:
@@ -200,17 +212,22 @@ class Trainer:
             row.update(beta=self.beta, alpha=self.alpha)
         self.pending_logs.append((res.loss, row))
         self.optimizer.zero_grad()
-        d_img_e = ops.l2norm_bwd(img_n, inv_i, res.d_img)
-        d_txt_e = ops.l2norm_bwd(txt_n, inv_t, res.d_txt)
-        for k, sl in enumerate(reversed(parts)):         # last micro-batch first: its activations are still in the towers' buffers
-            if k > 0:
-                towers(sl)                               # the activations of this micro-batch, saved for its backward
-            di, dt = d_img_e[sl].contiguous(), d_txt_e[sl].contiguous()
-            self.text_stream.wait_stream(main)
-            with torch.cuda.stream(self.text_stream):
-                m.text_backward(dt)                      # the first micro-batch overwrites the gradient buffer, the others accumulate
-            m.image_backward(di)
-            main.wait_stream(self.text_stream)
+        d_img_e = ops.l2norm_bwd(img_n, inv_i, res.d_img if sharded else D.local_rows(res.d_img))
+        d_txt_e = ops.l2norm_bwd(txt_n, inv_t, res.d_txt if sharded else D.local_rows(res.d_txt))
+        comm = m.comm
+        try:
+            for k, sl in enumerate(reversed(parts)):     # last micro-batch first: its activations are still in the towers' buffers
+                if k > 0:
+                    towers(sl)                           # the activations of this micro-batch, saved for its backward
+                di, dt = d_img_e[sl].contiguous(), d_txt_e[sl].contiguous()
+                m.comm = comm if k == len(parts) - 1 else None      # a bucket is all-reduced once, when the LAST micro-batch has added to it
+                self.text_stream.wait_stream(main)
+                with torch.cuda.stream(self.text_stream):
+                    m.text_backward(dt)                  # the first micro-batch overwrites the gradient buffer, the others accumulate
+                m.image_backward(di)
+                main.wait_stream(self.text_stream)
+        finally:
+            m.comm = comm
         if self.learnable_t and res.d_temp is not None:
             self.temperature.grad = res.d_temp.detach().cpu().reshape(())
         self.sync.wait_all()

@@ -38,7 +38,7 @@ def _batches(steps, model="tiny", batch=8):
     return [synthetic_batch(300 + k, batch, c["image_size"], c["ctx"], c["vocab"]) for k in range(steps)]
 
 
-def _run(rank, world, port, out, model_name="tiny", batch=8):
+def _run(rank, world, port, out, model_name="tiny", batch=8, micro=0):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       SC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     from sparsify_clip_amd import dist as D
@@ -51,23 +51,28 @@ def _run(rank, world, port, out, model_name="tiny", batch=8):
     losses = []
     for images, tokens in _batches(3, model_name, batch):
         a, b = D.shard_bounds(batch, rank, world)
-        losses.append(tr.step(images[a:b].cuda(), tokens[a:b].cuda()).item())
+        if micro:      # the rank's shard by micro-batches (Trainer.step_cached): each gradient bucket all-reduced once
+            losses.append(tr.step_cached(images[a:b].cuda(), tokens[a:b].cuda(), micro).item())
+        else:
+            losses.append(tr.step(images[a:b].cuda(), tokens[a:b].cuda()).item())
     out[rank] = (losses, model.param(_PROBE[model_name]).cpu(), model.param("token_embedding.weight").cpu())
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_name,batch", [("tiny", 8), ("test-small", 128), ("test-rn", 8)])
-def test_dp2_step_equals_dp1_step(model_name, batch):
+@pytest.mark.parametrize("model_name,batch,micro", [("tiny", 8, 0), ("test-small", 128, 0), ("test-rn", 8, 0), ("test-small", 128, 16), ("tiny", 8, 2)])
+def test_dp2_step_equals_dp1_step(model_name, batch, micro):
     """("test-small", 128): 64 pairs per rank and a 128-wide embedding - the shapes the SHARDED loss head takes (each rank its rows x
     all columns, statistics exchanged through dist.exchange_packets); ("tiny", 8) runs the replicated loss head; ("test-rn", 8): the
-    ModifiedResNet tower, whose BatchNorm statistics and gradient sums are exchanged so that two ranks reproduce the whole-batch statistics."""
+    ModifiedResNet tower, whose BatchNorm statistics and gradient sums are exchanged so that two ranks reproduce the whole-batch statistics.
+    micro > 0: every rank runs its shard through Trainer.step_cached (micro-batches, one loss head over the gathered global batch, each gradient
+    bucket all-reduced once behind the last micro-batch) - still the single-process step on the whole batch."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from sparsify_clip_amd.model import ClipModel
     from sparsify_clip_amd.train import Trainer
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    mp.spawn(_run, args=(2, _free_port(), out, model_name, batch), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, _free_port(), out, model_name, batch, micro), nprocs=2, join=True)
     ref_model = ClipModel(model_name, device="cuda:0", precision="fp32", seed=7)     # rank 0's initialisation
     tr = Trainer(_cfg(model_name, batch), "cuda:0", 4, model=ref_model)
     want = [tr.step(i.cuda(), t.cuda()).item() for i, t in _batches(3, model_name, batch)]
