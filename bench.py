@@ -49,7 +49,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=8)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--local-batch", type=int, default=1024)
+    p.add_argument("--local-batch", type=int, default=None, help="pairs per forward/backward pass of a rank (default 1024).  Given WITHOUT --global-batch it "
+                   "selects weak scaling: this many pairs per GPU and step (the per-GPU shards of BASELINE's other configurations, RN50, fp32)")
     p.add_argument("--model", type=str, default="ViT-B-32")
     p.add_argument("--experiment", type=str, default="experiment_6", help="which reference YAML (by prefix) supplies loss_type & co.")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
@@ -60,14 +61,20 @@ def parse():
     p.add_argument("--text-trim", type=int, default=1, help="N = 1 only: after the timed region, time the step again with `text_trim: True` (the "
                    "text tower runs over the batch's longest caption instead of all 77 positions; same results) and report it as 'with_text_trim'; "
                    "the headline value always computes every position, as the reference does")
-    p.add_argument("--global-batch", type=int, default=0, help="STRONG scaling instead of the default weak scaling: this global batch is split over "
-                   "the N ranks (SURVEY 8d: 8192 at 1 / 2 / 4 / 8 GPUs); a rank whose share exceeds --local-batch runs it by micro-batches of "
-                   "--local-batch through Trainer.step_cached (same step, ~4/3 of the encoder work).  0 = weak scaling (--local-batch pairs per GPU)")
+    p.add_argument("--global-batch", type=int, default=None, help="the step's global batch, split over the N ranks (default: 8192, BASELINE.json's metric, at "
+                   "every N = strong scaling); a rank whose share exceeds --local-batch runs it by micro-batches of --local-batch through "
+                   "Trainer.step_cached (the same step; activations of as many micro-batches as fit stay resident, the rest is forwarded twice).  "
+                   "0 = weak scaling (--local-batch pairs per GPU)")
     p.add_argument("--global-batch-one-gpu", type=int, default=8192, help="N = 1 only: after the timed region, time the metric's global batch as ONE step on "
                    "this GPU through Trainer.step_cached (micro-batches of --local-batch); 0 = off")
     p.add_argument("--simulate-dp", type=int, default=8, help="N = 1 only: after the timed region, time the step again with the loss head fed a "
                    "global batch of simulate_dp x local_batch rows (filler rows for the absent ranks) = the per-GPU work of that DP job; 1 = off")
-    return p.parse_args()
+    args = p.parse_args()
+    if args.global_batch is None:      # the metric's configuration unless the caller asked for a per-GPU batch
+        args.global_batch = 8192 if args.local_batch is None else 0
+    if args.local_batch is None:
+        args.local_batch = 1024
+    return args
 
 
 def reference_config(prefix, model, global_batch, precision):
@@ -159,9 +166,10 @@ def gemm_roofline(model, device):
             t = json.load(f)
         if t.get("launches") == count and t.get("local_batch") == model.visual.batch:
             traffic = t["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt_pers_kernel (persistent 256x256 AGPR kernel; every NT launch of one step with its fused epilogue)",
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_pers_kernel (persistent 256x256 AGPR kernel; every NT launch of one forward + backward pass over "
+                                     f"{model.visual.batch} pairs with its fused epilogue - a step is one such pass per micro-batch, plus the second forwards)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": count,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_pass": count,
             "avg_launch_us": round(total_ms * 1e3 / count, 1), "flops_per_launch_avg": total_flops / count,
             "algorithmic_bytes_per_launch_avg": sum(gemm_launch_bytes(m, n, k, kind) * reps for (m, n, k), kind, reps in launches) / count}
 
@@ -234,10 +242,14 @@ def main():
     trainer = Trainer(cfg, device, steps_per_epoch=1000)
     trainer.epoch = max(1, cfg["only_lunif_epochs"])       # main phase: the full loss stack, not the warm-up branch
     c = trainer.model.cfg
-    if strong:      # big shards: token rows from the seeded generator, pixels drawn on the device (i.i.d. N(0, 1) as SURVEY 8d, another stream)
-        gen = torch.Generator(device=device).manual_seed(42 + rank)
-        batches = [(torch.randn(rank_batch, 3, c["image_size"], c["image_size"], device=device, generator=gen),
-                    synthetic_batch(42 + rank + 100 * k, rank_batch, 8, c["ctx"], c["vocab"])[1].to(device)) for k in range(2)]
+    if strong and rank_batch > args.local_batch and trainer.model.rn is not None:
+        raise SystemExit(f"bench.py: {args.model} normalises over the batch (BatchNorm): a {rank_batch}-pair shard cannot run by micro-batches; "
+                         f"pass --local-batch (weak scaling) for it")
+    if strong:      # big shards: token rows from the seeded generator, pixels drawn on the device (i.i.d. N(0, 1) as SURVEY 8d, another stream);
+        gen = torch.Generator(device=device).manual_seed(42 + rank)      # the two batches share the 4.9 GB of pixels, in another order
+        pixels = torch.randn(rank_batch, 3, c["image_size"], c["image_size"], device=device, generator=gen)
+        batches = [(pixels, synthetic_batch(42 + rank + 100 * k, rank_batch, 8, c["ctx"], c["vocab"])[1].to(device)) for k in range(2)]
+        del pixels
     else:
         batches = [tuple(t.to(device) for t in synthetic_batch(42 + rank + 100 * k, args.local_batch, c["image_size"], c["ctx"], c["vocab"])) for k in range(2)]
     cached = strong and rank_batch > args.local_batch and rank_batch % args.local_batch == 0
@@ -270,16 +282,36 @@ def main():
     out = {"metric": "image-text pairs/sec", "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-           "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, local batch {rank_batch}/GPU"
-                                  + (f" by micro-batches of {args.local_batch} (Trainer.step_cached)" if cached else "") +
-                                  f", global batch {global_batch}, AdamW, random-init weights; "
-                                  + ("strong scaling: the global batch is fixed over N " if strong else "weak scaling: N = 8 is the metric's global batch 8192 ") +
-                                  f"(8192 pairs on ONE GPU need ~280 GB of saved activations + weights: does not fit 288 GB; see dp_rank_equivalent for one rank's work "
-                                  f"of that job and global_batch_one_gpu for the whole 8192-pair step on this GPU by micro-batches)",
-                      "global_batch": global_batch, "local_batch": rank_batch, "parallelism": f"dp{world}"},
+           "config": {"workload": f"{os.path.basename(key)} (loss_type {cfg['loss_type']!r}, main phase), {args.model}, global batch {global_batch}, "
+                                  f"{rank_batch} pairs per GPU" + (f" run by micro-batches of {args.local_batch} (Trainer.step_cached: embeddings of every "
+                                  f"micro-batch, ONE loss head over the global batch, backward per micro-batch from resident activations where the card's "
+                                  f"memory holds them, after a second forward otherwise; same result as the plain step - the saved activations of 8192 pairs, "
+                                  f"~280 GB, do not fit one GPU)" if cached else "") + ", AdamW, random-init weights; "
+                                  + ("strong scaling: BASELINE.json's global batch at every N" if strong else
+                                     f"weak scaling: {args.local_batch} pairs per GPU, the per-GPU shard of an N-GPU job"),
+                      "global_batch": global_batch, "local_batch": rank_batch, "micro_batch": min(rank_batch, args.local_batch), "parallelism": f"dp{world}"},
            "last_loss": last_loss,
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
-    if world == 1 and not strong and args.simulate_dp > 1:
+    if world == 1 and strong and rank_batch > args.local_batch:
+        # N = 1 extras below describe ONE forward/backward pass of --local-batch pairs (the per-GPU shard of the 8-GPU job): free the parked
+        # activations and cut the batches down to that size
+        out["resident_micro_batches"] = getattr(trainer, "_sets_n", 1)
+        trainer.model.drop_activation_sets()
+        batches = [(b[0][: args.local_batch].clone(), b[1][: args.local_batch].clone()) for b in batches]
+        torch.cuda.empty_cache()
+        for i in range(2):
+            trainer.step(*batches[i % 2])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nsh = min(args.steps, 8)
+        for i in range(nsh):
+            trainer.step(*batches[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / nsh
+        out["shard_step"] = {"local_batch": args.local_batch, "ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(args.local_batch / dt, 1),
+                             "note": "the plain step over --local-batch pairs (what one rank of the 8-GPU job runs, Trainer.step; the line bench.py printed as "
+                                     "`value` until the global batch ran on one GPU)"}
+    if world == 1 and args.simulate_dp > 1:
         # what ONE rank of a simulate_dp-GPU job computes per step (its row block of the global-batch loss head included; no collective)
         D.simulate_world(args.simulate_dp)
         trainer.step(*batches[0])
@@ -309,11 +341,15 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / 2
         del big_images, big_tokens
-        out["global_batch_one_gpu"] = {"global_batch": gb, "micro_batch": args.local_batch, "ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(gb / dt, 1),
+        resident = getattr(trainer, "_sets_n", 1)
+        trainer.model.drop_activation_sets()      # up to ~240 GB of parked activations: give them back before the next measurements
+        torch.cuda.empty_cache()
+        out["global_batch_one_gpu"] = {"global_batch": gb, "micro_batch": args.local_batch, "resident_micro_batches": resident, "ms_per_step": round(dt * 1e3, 3), "pairs_per_s": round(gb / dt, 1),
                                        "note": "the whole global-batch step on one GPU (Trainer.step_cached: embeddings of all micro-batches, ONE loss head over "
-                                               "every pair, then forward again + backward per micro-batch, one optimiser step); equal to step() up to fp32 summation "
+                                               "every pair, then backward per micro-batch - from its resident activations where the card's memory holds them, after "
+                                               "a second forward otherwise - one optimiser step); equal to step() up to fp32 summation "
                                                "order (tests/test_gpu_model.py::test_step_cached_equals_step); not the headline value"}
-    if world == 1 and not strong and args.text_trim:
+    if world == 1 and args.text_trim:
         # opt-in: text tower over the longest caption of the batch only (padding behind EOT cannot influence the result under the causal mask)
         from sparsify_clip_amd.data import caption_length
         lens = [caption_length(b[1]) for b in batches]
@@ -332,7 +368,7 @@ def main():
                                  "note": "config key text_trim: the text tower runs over the batch's longest caption (synthetic captions: 5-30 words + SOT/EOT, "
                                          "SURVEY 8d) rounded up to a multiple of 8 instead of all 77 positions; embeddings and gradients are the same "
                                          "(tests/test_gpu_model.py::test_text_trim_equivalence); not the headline value"}
-    if world == 1 and not strong and args.input_pipeline:
+    if world == 1 and args.input_pipeline:
         # the same step fed by the real input path: uint8 pixels -> pinned staging -> H2D on a side stream -> device crop/resize/flip/normalise
         from sparsify_clip_amd.input_pipeline import DeviceAugLoader, SyntheticCocoDataset
         nsteps = min(args.steps, 8)

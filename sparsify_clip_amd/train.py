@@ -145,14 +145,29 @@ class Trainer:
             self.flush_logs()
         return res.loss
 
-    def step_cached(self, images, captions, micro_batch):
+    def _resident_sets(self, n_micro, limit):
+        """How many micro-batches keep their activations on the card between the two passes of step_cached: as many as fit beside what is
+        already allocated (one set is known after the first forward), at most `limit`; decided once per shape."""
+        m = self.model
+        key = (n_micro, m.visual.batch, limit)
+        if getattr(self, "_sets_key", None) != key:
+            set_bytes = max(1, m.activation_set_bytes())
+            free, total = torch.cuda.mem_get_info(self.device)
+            free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)      # torch's cached, unused blocks
+            margin = max(8 << 30, total // 16)      # head-room: backward scratch of a first step, allocator fragmentation
+            fit = 1 + max(0, int((free - margin) // set_bytes))
+            self._sets_key, self._sets_n = key, max(1, min(n_micro, fit, limit or n_micro))
+        return self._sets_n
+
+    def step_cached(self, images, captions, micro_batch, resident_sets=None):
         """The SAME step for a batch whose saved activations do not fit the GPU (global batch 8192 of ViT-B/32 is ~280 GB of them):
         (1) both towers forward over micro-batches, keeping only the [B, E] embeddings; (2) the loss head ONCE over the whole batch -
         the O(B^2) terms see every pair, which plain gradient accumulation over micro-batches would not give; (3) per micro-batch the
         forward again (its activations saved this time) and the backward with its rows of dL/d(embedding), parameter gradients
-        accumulating in the flat buffer (the last micro-batch goes first: its activations are still there); (4) one optimiser step.  The
-        result equals step() on the whole batch up to fp32 summation order (tests/test_gpu_model.py::test_step_cached_equals_step) at
-        about 4/3 of its encoder work.  Under data parallelism `images` / `captions` are the rank's shard: embeddings gathered, loss head by rows,
+        accumulating in the flat buffer; (4) one optimiser step.  As many micro-batches as the card's memory holds keep their activations
+        between the passes (ClipModel.activation_set; `resident_sets` caps the number, 1 = only the last one) and skip the second forward.
+        The result equals step() on the whole batch up to fp32 summation order (tests/test_gpu_model.py::test_step_cached_equals_step) at
+        between 1x and 4/3 of its encoder work.  Under data parallelism `images` / `captions` are the rank's shard: embeddings gathered, loss head by rows,
         each gradient bucket all-reduced once (behind the last micro-batch's backward).  LayerNorm models only: BatchNorm statistics of a
         micro-batch are not the batch's."""
         cfg, m = self.config, self.model
@@ -180,10 +195,14 @@ class Trainer:
         e = m.cfg["embed_dim"]
         img_e = torch.empty(batch, e, dtype=torch.float32, device=self.device)
         txt_e = torch.empty(batch, e, dtype=torch.float32, device=self.device)
-        for sl in parts:
+        n, keep = len(parts), 1
+        for idx, sl in enumerate(parts):
+            m.activation_set(idx % keep)
             ie, te = towers(sl)
             img_e[sl].copy_(ie)
             txt_e[sl].copy_(te)
+            if idx == 0:
+                keep = self._resident_sets(n, resident_sets)      # micro-batches n - keep .. n - 1 stay resident for the second pass
         # from here to the embedding gradients: exactly step() - under data parallelism `images` is this rank's shard, the embeddings of
         # all ranks are gathered and the loss head (by rows, or replicated) sees the global batch
         send = D.gather_send_buffer(batch, e, img_e.device)[0] if D.active() else (None, None)
@@ -216,11 +235,13 @@ class Trainer:
         d_txt_e = ops.l2norm_bwd(txt_n, inv_t, res.d_txt if sharded else D.local_rows(res.d_txt))
         comm = m.comm
         try:
-            for k, sl in enumerate(reversed(parts)):     # last micro-batch first: its activations are still in the towers' buffers
-                if k > 0:
-                    towers(sl)                           # the activations of this micro-batch, saved for its backward
+            for idx in reversed(range(n)):               # the resident micro-batches first (their sets are free for the others afterwards)
+                sl = parts[idx]
+                m.activation_set(idx % keep)
+                if idx < n - keep:
+                    towers(sl)                           # not resident: the forward again, activations saved for this backward
                 di, dt = d_img_e[sl].contiguous(), d_txt_e[sl].contiguous()
-                m.comm = comm if k == len(parts) - 1 else None      # a bucket is all-reduced once, when the LAST micro-batch has added to it
+                m.comm = comm if idx == 0 else None      # a bucket is all-reduced once, when the LAST micro-batch processed has added to it
                 self.text_stream.wait_stream(main)
                 with torch.cuda.stream(self.text_stream):
                     m.text_backward(dt)                  # the first micro-batch overwrites the gradient buffer, the others accumulate

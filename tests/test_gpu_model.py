@@ -479,7 +479,8 @@ def test_step_cached_equals_step(pkg, experiment, precision):
     raw = cfgs[[k for k in cfgs if experiment in k][0]]
     name, batch = "test-small", 32
     runs = {}
-    for mode in ("whole", "cached"):
+    # resident activation sets between the two passes: 1 = only the last micro-batch (three recomputed), 2, as many as fit (all four: none recomputed)
+    for mode in ("whole", "cached-1", "cached-2", "cached-auto"):
         cfg = finalize_config(raw, 0, {"model": name, "batch_size": batch, "precision": precision})
         tr = Trainer(cfg, DEV, 10, model=pkg.ClipModel(name, device=DEV, precision=precision, seed=5))
         tr.epoch = 1
@@ -487,14 +488,19 @@ def test_step_cached_equals_step(pkg, experiment, precision):
         losses = []
         for k in range(3):
             images, tokens = [t.to(DEV) for t in synthetic_batch(90 + k, batch, c["image_size"], c["ctx"], c["vocab"])]
-            loss = tr.step(images, tokens) if mode == "whole" else tr.step_cached(images, tokens, 8)
+            keep = {"1": 1, "2": 2, "auto": None}.get(mode.split("-")[-1])
+            loss = tr.step(images, tokens) if mode == "whole" else tr.step_cached(images, tokens, 8, resident_sets=keep)
             losses.append(loss.item())
         torch.cuda.synchronize()
         runs[mode] = (losses, tr.model.flat.clone())
-        if mode == "cached":
+        if mode == "cached-auto":
+            assert tr._sets_n == 4 and len(tr.model.visual.sets) == 4      # everything fits at this size: four sets, nothing recomputed
             with pytest.raises(ScError):
                 tr.step_cached(images, tokens, 5)      # 32 is not a multiple of 5
+            tr.model.drop_activation_sets()
+            assert np.isfinite(tr.step(images, tokens).item())      # the plain step still runs on the current set
     tol_l, tol_p = (2e-6, 2e-5) if precision == "fp32" else (2e-2, 5e-2)
-    for a, b in zip(*[r[0] for r in runs.values()]):
-        assert abs(a - b) <= tol_l * abs(a), runs
-    assert rel_err(runs["cached"][1], runs["whole"][1]) < tol_p
+    for mode in ("cached-1", "cached-2", "cached-auto"):
+        for a, b in zip(runs["whole"][0], runs[mode][0]):
+            assert abs(a - b) <= tol_l * abs(a), (mode, runs)
+        assert rel_err(runs[mode][1], runs["whole"][1]) < tol_p, mode
