@@ -3,7 +3,7 @@
 # Tasks run in the order given and stop at the first failing one.  Everything logs under gpurun_out/ (merged back by gpurun);
 # what should be judged is copied from there into profiles/ by hand.  rocprofv3 always gets the python program directly after `--`.
 #   tests        python -m pytest tests -m gpu            -> gpurun_out/pytest_gpu.log            (PYTEST_ARGS to narrow)
-#   bench        python bench.py                          -> gpurun_out/bench.json / bench.err    (BENCH_ARGS, STEPS)
+#   bench        python bench.py (default: global batch 8192; BENCH_ARGS="--local-batch 1024" = the 1024-pair shard) -> gpurun_out/bench.json / bench.err    (BENCH_ARGS, STEPS)
 #   prof         rocprofv3 --kernel-trace --stats of bench.py (3 steps)          -> gpurun_out/prof/bench_kernel_stats.csv
 #   replay       rocprofv3 --kernel-trace --stats of tools/gemm_replay.py (ONE stream: bench.py's roofline launch set)
 #                                                         -> gpurun_out/replay/replay_kernel_stats.csv + per-shape table
@@ -21,6 +21,7 @@
 #                                                         -> gpurun_out/gemm_corun.txt
 #   ln           tools/ln_bench.py stand-alone LayerNorm forward / backward rates -> gpurun_out/layernorm_times.txt
 #   pipeline     tools/pipeline_bench.py: the input stage per phase (host assembly, H2D, loader alone, the step fed by the loader) -> gpurun_out/pipeline_bench.txt
+#   dp2s         the same rehearsal in the default strong-scaling form (global batch split over the ranks, shards by micro-batches) -> gpurun_out/dp2s.json
 #   dp2          python bench.py --gpus 2 under SC_DIST_BACKEND=gloo on the one GPU (self-launch rehearsal) -> gpurun_out/dp2.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof $R/gpurun_out/pmc $R/gpurun_out/replay
@@ -44,6 +45,10 @@ for task in "$@"; do
     dp2)
       SC_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --warmup 1 --local-batch ${DP2_BATCH:-256} > gpurun_out/dp2.json 2> gpurun_out/dp2.err; rc=$?
       echo "dp2 rc=$rc"; tail -3 gpurun_out/dp2.err; cat gpurun_out/dp2.json
+      [ $rc = 0 ] || exit $rc ;;
+    dp2s)   # the default (strong-scaling) form with two ranks: each runs its 1024-pair shard by micro-batches of 512 through Trainer.step_cached
+      SC_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --global-batch 2048 --local-batch 512 --steps 2 --warmup 1 > gpurun_out/dp2s.json 2> gpurun_out/dp2s.err; rc=$?
+      echo "dp2s rc=$rc"; tail -3 gpurun_out/dp2s.err; cut -c1-400 gpurun_out/dp2s.json
       [ $rc = 0 ] || exit $rc ;;
     prof)
       (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --simulate-dp 1 --global-batch-one-gpu 0 ${BENCH_ARGS} > $R/gpurun_out/rocprof.log 2>&1); rc=$?
