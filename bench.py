@@ -254,17 +254,33 @@ def main():
         batches = [tuple(t.to(device) for t in synthetic_batch(42 + rank + 100 * k, args.local_batch, c["image_size"], c["ctx"], c["vocab"])) for k in range(2)]
     cached = strong and rank_batch > args.local_batch and rank_batch % args.local_batch == 0
 
+    resident_cap = [None]      # None = as many micro-batches' activations as Trainer._resident_sets finds room for
+
     def run_step(b):
-        return trainer.step_cached(*b, args.local_batch) if cached else trainer.step(*b)
+        return trainer.step_cached(*b, args.local_batch, resident_sets=resident_cap[0]) if cached else trainer.step(*b)
 
     def barrier():
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run_step(batches[i % 2])
-        torch.cuda.synchronize()
+    for i in range(max(args.warmup, 1 if cached else 0)):
+        try:
+            run_step(batches[i % 2])
+            torch.cuda.synchronize()
+        except torch.cuda.OutOfMemoryError:
+            # the memory estimate was too optimistic for this card's state (another context, fragmentation): park fewer micro-batches and go on;
+            # an interrupted step leaves half-accumulated gradients behind, which the next step overwrites
+            if not cached:
+                raise
+            kept = getattr(trainer, "_sets_n", 2)
+            resident_cap[0] = max(1, kept // 2)
+            progress(f"out of device memory with {kept} resident micro-batches: retrying with {resident_cap[0]}")
+            trainer.model.activation_set(0)
+            trainer.model.drop_activation_sets()
+            torch.cuda.empty_cache()
+            run_step(batches[i % 2])
+            torch.cuda.synchronize()
         progress(f"warm-up step {i + 1}/{args.warmup} done")
     barrier()
     t0 = time.perf_counter()
