@@ -504,3 +504,37 @@ def test_step_cached_equals_step(pkg, experiment, precision):
         for a, b in zip(runs["whole"][0], runs[mode][0]):
             assert abs(a - b) <= tol_l * abs(a), (mode, runs)
         assert rel_err(runs[mode][1], runs["whole"][1]) < tol_p, mode
+
+
+def test_step_cached_real_size_bf16(pkg):
+    """Trainer.step_cached at the benchmarked size and precision (ViT-B/32, bf16, micro-batches of 1024, the persistent GEMMs with tile
+    tickets, four streams): a 2048-pair step by two micro-batches - the first re-forwarded (resident_sets = 1) or both resident - against
+    the plain 2048-pair step from the same seed.  The first step's loss is BIT-equal (the embeddings of a pair do not depend on which
+    pass computed them: a micro-batch runs the kernels of a 1024-pair step); later steps differ by the summation order of the gradient
+    accumulation only (bf16 level); the two cached variants agree bit for bit with each other (same order of everything)."""
+    from conftest import load_json
+    from sparsify_clip_amd.config import finalize_config
+    from sparsify_clip_amd.data import synthetic_batch
+    from sparsify_clip_amd.train import Trainer
+    cfgs = load_json("configs.json")
+    raw = cfgs[[k for k in cfgs if "experiment_6-" in k][0]]
+    cfg = finalize_config(raw, 0, {"model": "ViT-B-32", "batch_size": 2048, "precision": "bf16"})
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    images = torch.randn(2048, 3, 224, 224, device=DEV, generator=gen)
+    tokens = synthetic_batch(43, 2048, 8)[1].to(DEV)
+    runs = {}
+    for mode in ("whole", "cached-1", "cached-2"):
+        tr = Trainer(cfg, DEV, 1000)
+        tr.epoch = 1
+        step = (lambda: tr.step(images, tokens)) if mode == "whole" else (lambda: tr.step_cached(images, tokens, 1024, resident_sets=int(mode[-1])))
+        losses = [step().item() for _ in range(3)]
+        torch.cuda.synchronize()
+        runs[mode] = (losses, tr.model.flat.clone())
+        del tr, step
+        torch.cuda.empty_cache()
+    assert runs["cached-1"][0] == runs["cached-2"][0] and torch.equal(runs["cached-1"][1], runs["cached-2"][1])
+    assert runs["whole"][0][0] == runs["cached-2"][0][0], (runs["whole"][0], runs["cached-2"][0])
+    for a, b in zip(runs["whole"][0], runs["cached-2"][0]):
+        assert abs(a - b) <= 2e-2 * abs(a), runs
+    assert rel_err(runs["cached-2"][1], runs["whole"][1]) < 5e-2
+    assert all(np.isfinite(x) for x in runs["cached-2"][0]) and runs["cached-2"][0][0] != runs["cached-2"][0][2]
