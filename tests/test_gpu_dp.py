@@ -107,6 +107,9 @@ def _run_rccl_world1(rank, port, out):
             model = ClipModel("tiny", device="cuda:0", precision=precision, seed=7)
             tr = Trainer(cfg, "cuda:0", 4, model=model)
             losses = [tr.step(i.cuda(), t.cuda()).item() for i, t in _batches(3)]
+            # the micro-batched form of the step (what a rank with a shard > 1024 pairs runs): gather, row-block loss head and the bucket
+            # all-reduces behind the last micro-batch, all through the backend
+            losses += [tr.step_cached(i.cuda(), t.cuda(), 4, resident_sets=1).item() for i, t in _batches(2)]
             torch.cuda.synchronize()
             runs.append((losses, model.flat.clone()))
         res[precision] = (runs[0][0] == runs[1][0], bool(torch.equal(runs[0][1], runs[1][1])), runs[1][0])
