@@ -306,7 +306,7 @@ def main():
                                   + ("strong scaling: BASELINE.json's global batch at every N" if strong else
                                      f"weak scaling: {args.local_batch} pairs per GPU, the per-GPU shard of an N-GPU job"),
                       "global_batch": global_batch, "local_batch": rank_batch, "micro_batch": min(rank_batch, args.local_batch), "parallelism": f"dp{world}"},
-           "last_loss": last_loss,
+           "last_loss": last_loss, "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
            "step_mfma_frac": round(pairs_per_s * GF_PER_PAIR.get(args.model, 0.0) / 1e3 / (world * PEAK_BF16_TFLOPS), 4)}
     if world == 1 and strong and rank_batch > args.local_batch:
         # N = 1 extras below describe ONE forward/backward pass of --local-batch pairs (the per-GPU shard of the 8-GPU job): free the parked
