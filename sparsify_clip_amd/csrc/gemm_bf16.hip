@@ -446,6 +446,13 @@ __device__ __forceinline__ f32x4 ntb_acc() {   // accumulator tile T = 4 i + j
                  : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2), "n"(4 * T + 3) : SC_ACC_AGPRS);
     return v;
 }
+// accumulator tile T -> LDS (16 bytes per lane at byte address `lds`) straight from the AGPRs: DS instructions take AGPR data operands,
+// so the 128 v_accvgpr_read of a tile's read-back (and their VGPRs) are not needed.  Ordered against the compiler's own LDS accesses
+// by the "memory" clobber; LDS operations of one wave execute in issue order, so the slab reads behind it see the data.
+template <int T>
+__device__ __forceinline__ void ntb_acc_to_lds(unsigned lds) {
+    asm volatile("ds_write_b128 %0, a[%1:%2]" : : "v"(lds), "n"(4 * T), "n"(4 * T + 3) : "memory", SC_ACC_AGPRS);
+}
 template <int T, int H>
 __device__ __forceinline__ void ntb_to_slab(float* slab_lane) {   // rows 64 H .. 64 H + 63 of the wave's sub-tile: i = 4 H + T / 4, j = T % 4
     *(f32x4*)(slab_lane + (16 * (T / 4)) * 68 + 16 * (T % 4)) = ntb_acc<16 * H + T>();
@@ -679,7 +686,7 @@ struct NtpEpi {   // per-tile epilogue context: uniform bases (SGPRs) + this lan
     char* pre;              // pre_out (bf16), same origin
     unsigned row_bytes_c, row_bytes_aux, row_bytes_pre;   // bytes per matrix row
     unsigned voff_c, voff_aux, voff_pre;                  // lane: (erow * ld + ecol) * element size
-    char* slab_wr;          // slab + frow * 256
+    unsigned slab_wr[4];    // LDS byte addresses of this lane's four 16-byte pieces (MFMA ownership) of a row tile in the slab
     const char* slab;       // wave's slab
     f32x4 bias0, bias1;
 };
@@ -710,11 +717,11 @@ __device__ __forceinline__ void ntp_aux_load(NtpAux<EPI>& x, const NtpEpi& c) {
 // slab -> registers (row-major ownership: row lane >> 3 (+8), 8 columns 8 (lane & 7) ..), epilogue arithmetic, 16-byte stores.
 template <int EPI, int I>
 __device__ __forceinline__ void ntp_row_tile(const NtpEpi& c, int lane, const NtpAux<EPI>& x, bool do_cs, f32x4& cs0, f32x4& cs1) {
-    const int frow = lane & 15, fq = lane >> 4, erow = lane >> 3, ep = lane & 7;
-    *(f32x4*)(c.slab_wr + (((0 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 0>();
-    *(f32x4*)(c.slab_wr + (((4 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 1>();
-    *(f32x4*)(c.slab_wr + (((8 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 2>();
-    *(f32x4*)(c.slab_wr + (((12 + fq) ^ frow) << 4)) = ntb_acc<4 * I + 3>();
+    const int erow = lane >> 3, ep = lane & 7;
+    ntb_acc_to_lds<4 * I + 0>(c.slab_wr[0]);
+    ntb_acc_to_lds<4 * I + 1>(c.slab_wr[1]);
+    ntb_acc_to_lds<4 * I + 2>(c.slab_wr[2]);
+    ntb_acc_to_lds<4 * I + 3>(c.slab_wr[3]);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int row = 8 * g + erow;
@@ -852,6 +859,11 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
                                              int& vn) {
     constexpr int NG = HALF ? 4 : 8;
     constexpr bool OUT_F32 = EPI == NTP_RESID;
+    // vector-memory operations every wave issues in the epilogue of a tile, at least: per 16-row tile two 8-row groups with one (bias, GELU')
+    // or two (GELU + pre-activation, fp32) 16-byte stores and, for GELU' / the residual, as many operand loads.  A half tile may follow a
+    // whole one, never the other way round, so the half tile's count serves both.  The counter holds 6 bits.
+    constexpr int NV_FULL = EPI == NTP_BIAS ? 16 : EPI == NTP_RESID ? 60 : 32;
+    constexpr int NV = HALF ? (EPI == NTP_BIAS ? 8 : EPI == NTP_RESID ? 32 : 16) : NV_FULL;
     const int wm = wave >> 2, wn = wave & 3;
     const GemmBf16Params& p = ntp_args();   // main loop and tile walk: A, B, lda, ldb, tiles_*, group_*, half_*
     bf16x8 a[8], b0[4], b1[4];
@@ -867,7 +879,8 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
     do {                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
         ntb_substep<0, true, false, NG>(a, b0, b1, A_S1, B_S1);                                       \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        if ((S) == 0 && (KT) == 0 && !first) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NV) : "memory");   /* K-tile 1 is older than the previous epilogue's stores */ \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
         if ((HOOK) && (S) == 1 && tickets && wave == 0 && (KT) == 1) ntp_ticket_publish(box, ticket); \
         __builtin_amdgcn_s_barrier();                                                                 \
         if ((KT) + 2 < nk) ntp_stage(p, cur, S, (KT) + 2, lds0, wave, oa, ob);                    \
@@ -879,8 +892,15 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
     // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     if constexpr (STAMP) ts0 = ntp_stamp();
-    if (first && nk > 1 && !HALF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (first) {
+        if (nk > 1 && !HALF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // The stores (and operand loads) of the previous tile's epilogue were issued AFTER this tile's K-tiles 0 and 1 and the counter
+        // retires in issue order: with at most NV operations outstanding both K-tiles have landed while the youngest stores are still
+        // on their way to memory - they drain under K-tile 0 and the first half of K-tile 1 instead of holding the tile's start
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NV) : "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if constexpr (STAMP) ts1 = ntp_stamp();
     // same issue order as inside a sub-step (a0 b0 a1 b1 a2 b2 a3 b3 [a4 a5 a6 a7]): the loop's waits rely on it
@@ -956,7 +976,8 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
             c.voff_pre = (unsigned)((erow * e_ldc + ecol) * 2);
         }
         c.slab = smem + 2 * B_STAGE + wave * P_SLAB;
-        c.slab_wr = smem + 2 * B_STAGE + wave * P_SLAB + frow * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c.slab_wr[j] = lds0 + 2 * B_STAGE + wave * P_SLAB + frow * 256 + (((4 * j + fq) ^ frow) << 4);
         c.bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; c.bias1 = c.bias0;
         if (e_bias) { c.bias0 = *(const f32x4*)(e_bias + nw + ecol); c.bias1 = *(const f32x4*)(e_bias + nw + ecol + 4); }
         const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;

@@ -175,18 +175,25 @@ def test_gemm_bf16_nt_tile_tickets(ops, m, n, k):
 
 
 def test_gemm_bf16_epilogue_gelu_series_accuracy(ops):
-    """The bf16 epilogues evaluate GELU / GELU' as odd polynomial series (csrc/common.h); through an fp32-output GEMM with
-    acc == x (B = I) resp. acc == 1 the series are compared with the erf forms over [-9, 9]: abs error <= 2e-5 / 3e-5."""
+    """The bf16 epilogues evaluate GELU / GELU' as odd polynomial series (csrc/common.h; degree 6 / 7, fitted by
+    tools/fit_gelu_series.py); through an fp32-output GEMM with acc == x (B = I) resp. acc == 1 the series are compared with the erf
+    forms over [-9, 9].  The step rounds both results to bf16 (half an ulp = 2^-8 = 3.9e-3 relative), so the bounds are stated as
+    fractions of that rounding: GELU within 7.5e-5 |x| everywhere (the error of Phi) and within 1.5e-4 relative for x > 0 (1/26 of
+    the rounding); GELU' within 3e-4 absolute (1/13 of the rounding of a value near 1)."""
     m, k = 512, 64
     x = torch.linspace(-9, 9, m * k).reshape(m, k).to(torch.bfloat16)
     eye = torch.eye(k, dtype=torch.bfloat16)
-    got = ops.gemm_bf16_nt(x.to(DEV), eye.to(DEV), out_dtype=torch.float32, epi=ops.make_epilogue(act=1, ld_aux=k))
-    assert_close(got, gelu64(x.double()), 0, 2e-5, "GELU series")
+    got = ops.gemm_bf16_nt(x.to(DEV), eye.to(DEV), out_dtype=torch.float32, epi=ops.make_epilogue(act=1, ld_aux=k)).double().cpu()
+    want = gelu64(x.double())
+    err = (got - want).abs()
+    assert float((err - 7.5e-5 * x.double().abs()).max()) <= 1e-7, f"GELU series: max |err| / |x| = {float((err / x.double().abs().clamp_min(1e-3)).max()):.3e}"
+    pos = x.double() > 0
+    assert float((err[pos] / want[pos]).max()) <= 1.5e-4, "GELU series: relative error for x > 0"
     a = torch.zeros(m, k, dtype=torch.bfloat16); a[:, 0] = 1
     b = torch.zeros(k, k, dtype=torch.bfloat16); b[:, 0] = 1
     pre = x.to(DEV)
     got = ops.gemm_bf16_nt(a.to(DEV), b.to(DEV), out_dtype=torch.float32, epi=ops.make_epilogue(dgelu_pre=pre, ld_aux=k))
-    assert_close(got, gelu_grad64(x.double()), 0, 3e-5, "GELU' series")
+    assert_close(got, gelu_grad64(x.double()), 0, 3e-4, "GELU' series")
 
 
 @pytest.mark.parametrize("m,n,k", [(4100, 1544, 192), (8192, 768, 128), (300, 192, 128), (10300, 2056, 64)])

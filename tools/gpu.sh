@@ -13,6 +13,7 @@
 #   pmc_loss     FETCH_SIZE / WRITE_SIZE + kernel times of the loss head at B = 8192 -> gpurun_out/pmc/loss_counters.txt
 #   pmc_bn       tools/bn_one.py: BatchNorm + implicit-convolution kernels at RN50's first-stage shape: times, FETCH_SIZE / WRITE_SIZE
 #                                                         -> gpurun_out/bn_conv_times.txt, pmc/bn_conv_counters.txt
+#   stamps       tools/gemm_stamps.py: s_memtime stamps of the persistent NT kernel's diagnostic instances (per tile: wait / loop / epilogue) -> gpurun_out/gemm_tile_stamps.txt
 #   loss         tools/loss_bench.py                       -> gpurun_out/loss_head_times.txt
 #   attn / pmc_attn   tools/attn_bench.py timings / SQ counters of the attention kernels -> gpurun_out/attention_times.txt, pmc/attn_counters.txt
 #   configs      bench.py for BASELINE configs C2 / C3 / C5 (per-GPU shards), --precision fp32 and the YAMLs' own RN50 at batch 256
@@ -65,6 +66,8 @@ for task in "$@"; do
       [ $rc = 0 ] || exit $rc ;;
     gemm)
       timeout -k 10 600 python tools/gemm_bench.py > gpurun_out/gemm_shapes.txt 2>&1; rc=$?; cat gpurun_out/gemm_shapes.txt; [ $rc = 0 ] || exit $rc ;;
+    stamps)
+      timeout -k 10 300 python tools/gemm_stamps.py > gpurun_out/gemm_tile_stamps.txt 2>&1; rc=$?; cut -c1-330 gpurun_out/gemm_tile_stamps.txt; [ $rc = 0 ] || exit $rc ;;
     loss)
       timeout -k 10 600 python tools/loss_bench.py > gpurun_out/loss_head_times.txt 2>&1; rc=$?; cat gpurun_out/loss_head_times.txt; [ $rc = 0 ] || exit $rc ;;
     pmc_gemm)
