@@ -757,12 +757,26 @@ __device__ __forceinline__ void ntp_row_tile(const NtpEpi& c, int lane, const Nt
     }
 }
 
-template <int EPI, int I, int NP>
-__device__ __forceinline__ void ntp_epilogue_rows(const NtpEpi& c, int lane, const NtpAux<EPI>& cur, bool do_cs, f32x4& cs0, f32x4& cs1) {
-    NtpAux<EPI> nxt;
-    if constexpr (I + 1 < NP && (EPI == NTP_DGELU || EPI == NTP_RESID)) ntp_aux_load<EPI, I + 1>(nxt, c);
-    ntp_row_tile<EPI, I>(c, lane, cur, do_cs, cs0, cs1);
-    if constexpr (I + 1 < NP) ntp_epilogue_rows<EPI, I + 1, NP>(c, lane, nxt, do_cs, cs0, cs1);
+// The epilogue's global operands (GELU' pre-activation, fp32 residual) are requested D row tiles ahead, in a ring of D register sets.  The
+// vector-memory counter retires loads and stores in issue order, so a wait for the operands of row tile I also waits for every store
+// issued in front of their request: with the request of row tile I + D placed behind the stores of row tile I, a store has D row
+// tiles' time to reach memory before anything waits for it (D = 1, rounds 1-2: the out_proj / fc2 epilogues ran at the latency of
+// one store round trip per row tile, 11 B / clk / CU with the memory system far from saturated - delaying half of the workgroups by
+// half a tile period changed nothing, tools/desync_bench.py, round 3).
+template <int EPI> constexpr int ntp_aux_depth() { return EPI == NTP_RESID ? 3 : EPI == NTP_DGELU ? 4 : 1; }
+
+template <int EPI, int I, int NP, int D>
+__device__ __forceinline__ void ntp_epilogue_rows(const NtpEpi& c, int lane, NtpAux<EPI> (&ring)[D], bool do_cs, f32x4& cs0, f32x4& cs1) {
+    ntp_row_tile<EPI, I>(c, lane, ring[I % D], do_cs, cs0, cs1);
+    if constexpr (I + D < NP && (EPI == NTP_DGELU || EPI == NTP_RESID)) ntp_aux_load<EPI, I + D>(ring[I % D], c);
+    if constexpr (I + 1 < NP) ntp_epilogue_rows<EPI, I + 1, NP, D>(c, lane, ring, do_cs, cs0, cs1);
+}
+template <int EPI, int I, int NP, int D>
+__device__ __forceinline__ void ntp_aux_fill(NtpAux<EPI> (&ring)[D], const NtpEpi& c) {
+    if constexpr (I < D && I < NP) {
+        ntp_aux_load<EPI, I>(ring[I], c);
+        ntp_aux_fill<EPI, I + 1, NP, D>(ring, c);
+    }
 }
 
 __device__ __forceinline__ unsigned long long ntp_stamp() {
@@ -982,9 +996,10 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
         if (e_bias) { c.bias0 = *(const f32x4*)(e_bias + nw + ecol); c.bias1 = *(const f32x4*)(e_bias + nw + ecol + 4); }
         const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;
         f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
-        NtpAux<EPI> x0;
-        if constexpr (EPI == NTP_DGELU || EPI == NTP_RESID) ntp_aux_load<EPI, 0>(x0, c);
-        ntp_epilogue_rows<EPI, 0, NG>(c, lane, x0, do_cs, cs0, cs1);
+        constexpr int AD = ntp_aux_depth<EPI>() - (STAMP && ntp_aux_depth<EPI>() > 1 ? 1 : 0);   // the diagnostic instances keep their time stamps in registers
+        NtpAux<EPI> ring[AD];
+        if constexpr (EPI == NTP_DGELU || EPI == NTP_RESID) ntp_aux_fill<EPI, 0, NG, AD>(ring, c);
+        ntp_epilogue_rows<EPI, 0, NG, AD>(c, lane, ring, do_cs, cs0, cs1);
         if constexpr (EPI == NTP_DGELU) {
             if (do_cs) {   // the 8 row groups of a wave (lane bits 3..5) in a fixed order, then one partial row per 64-row slice of the output
 #pragma unroll
