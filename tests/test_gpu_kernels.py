@@ -505,6 +505,25 @@ def test_attention(ops, dtype, seq, heads, causal):
         assert_close(d_qkv, q64.grad, *tolb, "attention bwd")
 
 
+@pytest.mark.parametrize("seq,heads,causal", [(50, 12, False), (77, 8, True), (33, 5, True)])
+def test_attention_bwd_many_heads(ops, seq, heads, causal):
+    """The short-sequence backward is a persistent kernel (one workgroup per CU walks groups of four heads, the next group's operands
+    prefetched into registers): with 110 images x `heads` heads every workgroup runs several groups, the last one partly filled.
+    Against torch autograd in fp64 on the bf16-rounded inputs, with the fused in_proj bias gradient."""
+    batch, w = 110, heads * 64
+    qkv = rnd(batch * seq, 3 * w, seed=71).to(torch.bfloat16)
+    d_out = rnd(batch * seq, w, seed=72).to(torch.bfloat16)
+    q64 = qkv.double().requires_grad_(True)
+    _ref_attention(q64, batch, seq, heads, causal).backward(d_out.double())
+    _poison_lds()
+    cs = torch.zeros(3 * w, device=DEV)
+    got = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal, colsum_out=cs)
+    assert_close(got, q64.grad, 2e-2, 2e-2, "attention bwd, many heads")
+    assert_close(cs, got.double().sum(0), 1e-5, 2e-4, "attention bwd colsum, many heads")
+    again = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal)
+    assert torch.equal(again, got), "attention bwd: not bit-stable between launches / with and without the column sums"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("seq,heads,causal", [(50, 3, False), (77, 2, True), (16, 1, True), (257, 2, False)])
 def test_attention_bwd_fused_colsum(ops, dtype, seq, heads, causal):
