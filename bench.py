@@ -197,6 +197,47 @@ def cpu_baseline(cfg, model_name, batch):
             "sample": f"{n} full training steps of {model_name} fp32 at {batch} pairs/step (oracle/train_step.py, plain torch on the host cores)"}
 
 
+class simulated_world:
+    """Bench-only (N = 1): what ONE rank of a w-GPU job computes per step.  While active, the four places where the trainer meets
+    sparsify_clip_amd.dist see a world of w ranks with this process as rank 0: the embedding gather returns a [w * Bl, E] batch whose first
+    Bl rows are this rank's and whose other rows are fixed unit-norm filler, the loss head is sharded w ways (this rank's rows against
+    all columns), the statistics exchange returns w copies of this rank's packet.  No collective is simulated.  The patch lives here, not in the
+    product module."""
+
+    def __init__(self, w):
+        self.w, self.fill, self.saved = int(w), {}, {}
+
+    def _gather(self, local, which):
+        bl, e = local.shape
+        key = (bl, e, which, str(local.device))
+        full = self.fill.get(key)
+        if full is None:
+            g = torch.Generator(device="cpu").manual_seed(977 + which)
+            full = self.fill[key] = torch.nn.functional.normalize(torch.randn(self.w * bl, e, generator=g), dim=-1).to(local.device)
+        full[:bl].copy_(local)
+        return full
+
+    def __enter__(self):
+        from sparsify_clip_amd import dist as D
+        assert not D.active(), "simulated_world is for a process without a process group"
+        w = self.w
+        patch = {"all_gather_embeddings": lambda img, txt: (self._gather(img, 0), self._gather(txt, 1)),
+                 "sharding": lambda: (w, 0),
+                 "exchange_packets": lambda packet: packet.unsqueeze(0).expand(w, -1).contiguous(),
+                 "local_rows": lambda full: full[: full.shape[0] // w].contiguous()}
+        for name, fn in patch.items():
+            self.saved[name] = getattr(D, name)
+            setattr(D, name, fn)
+        return self
+
+    def __exit__(self, *exc):
+        from sparsify_clip_amd import dist as D
+        for name, fn in self.saved.items():
+            setattr(D, name, fn)
+        self.fill.clear()
+        return False
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (torch.distributed.run on 127.0.0.1) and
     relay rank 0's JSON line.  Decided before this process touches the GPU (no torch.cuda call, no library load); the parent
@@ -265,14 +306,18 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(max(args.warmup, 1 if cached else 0)):
+        step_state = (trainer.current_batch, list(trainer.pending_logs))
         try:
             run_step(batches[i % 2])
             torch.cuda.synchronize()
         except torch.cuda.OutOfMemoryError:
             # the memory estimate was too optimistic for this card's state (another context, fragmentation): park fewer micro-batches and go on;
-            # an interrupted step leaves half-accumulated gradients behind, which the next step overwrites
-            if not cached:
+            # an interrupted step leaves half-accumulated gradients behind, which the next step overwrites.  ONE rank only: with several
+            # ranks the interrupted step may already have issued its embedding all-gather / statistics exchange while the others sit in
+            # their bucket all-reduces - re-running it would mismatch the collective sequences, so the run fails instead
+            if not cached or world > 1:
                 raise
+            trainer.current_batch, trainer.pending_logs = step_state      # the retried step is the same step: same schedule position, one log row
             kept = getattr(trainer, "_sets_n", 2)
             resident_cap[0] = max(1, kept // 2)
             progress(f"out of device memory with {kept} resident micro-batches: retrying with {resident_cap[0]}")
@@ -329,16 +374,15 @@ def main():
                                      "`value` until the global batch ran on one GPU)"}
     if world == 1 and args.simulate_dp > 1:
         # what ONE rank of a simulate_dp-GPU job computes per step (its row block of the global-batch loss head included; no collective)
-        D.simulate_world(args.simulate_dp)
-        trainer.step(*batches[0])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        nsim = min(args.steps, 8)
-        for i in range(nsim):
-            trainer.step(*batches[i % 2])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / nsim
-        D.simulate_world(1)
+        with simulated_world(args.simulate_dp):
+            trainer.step(*batches[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nsim = min(args.steps, 8)
+            for i in range(nsim):
+                trainer.step(*batches[i % 2])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / nsim
         out["dp_rank_equivalent"] = {"simulated_world": args.simulate_dp, "loss_head_batch": args.simulate_dp * args.local_batch,
                                      "ms_per_step": round(dt * 1e3, 3), "pairs_per_s_per_gpu": round(args.local_batch / dt, 1),
                                      "note": "compute of one rank of the DP job: the loss head takes this rank's 1/world of the rows against the whole gathered batch "

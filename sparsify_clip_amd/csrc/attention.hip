@@ -23,12 +23,12 @@ namespace {
 
 // SC_ATTENTION=valu forces the fp32-VALU kernels for bf16 too (A/B runs)
 bool use_mfma() {
-    static const bool on = [] { const char* e = getenv("SC_ATTENTION"); return !(e && e[0] == 'v'); }();
+    static const bool on = [] { const char* e = sc_debug_env("SC_ATTENTION"); return !(e && e[0] == 'v'); }();
     return on;
 }
 // SC_ATTENTION_SHORT=2: the recompute (workgroup-per-head) kernels for short sequences too (A/B runs)
 bool short_recompute() {
-    static const bool on = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
+    static const bool on = [] { const char* e = sc_debug_env("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
     return on;
 }
 

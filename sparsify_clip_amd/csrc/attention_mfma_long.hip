@@ -641,12 +641,12 @@ int launch_bwd_long2(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
 // Returns 1 when the shape is not covered.
 int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
     if (seq > NT_LONG * 16) return 1;
-    static const bool short2 = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
+    static const bool short2 = [] { const char* e = sc_debug_env("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
     if (short2 && seq <= 64) return launch_fwd_long2<4, 4>(qkv, out, batch, seq, width, heads, causal, st);
     if (short2 && seq <= 80) return launch_fwd_long2<5, 5>(qkv, out, batch, seq, width, heads, causal, st);
     if (seq <= 64) return launch_fwd_block<4, 4>(qkv, out, batch, seq, width, heads, causal, st);
     if (seq <= 80) return launch_fwd_block<5, 5>(qkv, out, batch, seq, width, heads, causal, st);
-    static const bool old_long = [] { const char* e = getenv("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variants (A/B)
+    static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variants (A/B)
     if (old_long) return launch_fwd_block<NT_LONG, 4>(qkv, out, batch, seq, width, heads, causal, st);
     return launch_fwd_long2<NT_LONG, 8>(qkv, out, batch, seq, width, heads, causal, st);
 }
@@ -654,7 +654,7 @@ int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                           float* cs_part, hipStream_t st) {
     if (seq > NT_LONG * 16) return 1;
-    static const bool short2 = [] { const char* e = getenv("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();   // =2: recompute kernels for short sequences too (A/B)
+    static const bool short2 = [] { const char* e = sc_debug_env("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();   // =2: recompute kernels for short sequences too (A/B)
     if (short2 && seq <= 64) return launch_bwd_long2<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     if (short2 && seq <= 80) return launch_bwd_long2<5, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     if (seq <= 64) return launch_bwd_block<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
@@ -662,7 +662,7 @@ int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64
     // 4 waves (one per SIMD, 512 registers each): the backward keeps the scores and dP of all 17 key tiles of a query tile in
     // registers; with 8 waves (256 registers) it spills ~400 VGPRs.  At ViT-L/14 scale this kernel is 35 % of the step
     // (6.1 ms per layer at local batch 512): a recompute-per-key-tile formulation is the next step for that model.
-    static const bool old_long = [] { const char* e = getenv("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variant (A/B)
+    static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variant (A/B)
     if (old_long) return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     return launch_bwd_long2<NT_LONG, 8>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
 }

@@ -35,7 +35,7 @@ namespace {
 // SC_BLOCK_UNFUSE_GELU=1: GELU / GELU' as separate HBM-bound kernels instead of GEMM epilogues (A/B: the step is GEMM-bound and other
 // kernels run in the GEMMs' shadow, so moving epilogue work out of the GEMMs might pay; bf16 path only)
 bool unfuse_gelu() {
-    static const bool on = [] { const char* e = getenv("SC_BLOCK_UNFUSE_GELU"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char* e = sc_debug_env("SC_BLOCK_UNFUSE_GELU"); return e && e[0] == '1'; }();
     return on;
 }
 
@@ -187,12 +187,12 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     // after the other whichever stream they come from, so issuing them early only makes them queue between the
     // activation-gradient GEMMs, while the attention backward - latency bound, a few waves per CU - otherwise leaves the
     // MFMA units idle for its whole duration.
-    static const bool gate_env = [] { const char* e = getenv("SC_BLOCK_DW_GATE"); return !(e && e[0] == '0'); }();
+    static const bool gate_env = [] { const char* e = sc_debug_env("SC_BLOCK_DW_GATE"); return !(e && e[0] == '0'); }();
     const bool gate = two && gate_env;
     // SC_BLOCK_DW_GROUP=0: four separate weight-gradient launches (A/B); default: ONE grouped launch per block, after the attention
     // backward, when the bias gradients are taken elsewhere (fcs) and the rows are whole K-tiles
-    static const bool group_env = [] { const char* e = getenv("SC_BLOCK_DW_GROUP"); return !(e && e[0] == '0'); }();
-    const bool fcs_early = bf && [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();
+    static const bool group_env = [] { const char* e = sc_debug_env("SC_BLOCK_DW_GROUP"); return !(e && e[0] == '0'); }();
+    const bool fcs_early = bf && [] { const char* e = sc_debug_env("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();
     const bool grouped = group_env && fcs_early && rows % 64 == 0;
     // ---- MLP half: c_proj, GELU', c_fc
     if (!gate && !grouped) {
@@ -200,7 +200,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
         SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
     }
     if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));   // reads the fp32 dx_out: main stream
-    static const bool fuse_cs = [] { const char* e = getenv("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum passes (A/B runs)
+    static const bool fuse_cs = [] { const char* e = sc_debug_env("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum passes (A/B runs)
     const bool fcs = bf && fuse_cs;
     EpiParams e = epi_plain();
     const bool ug = bf && fcs && unfuse_gelu();

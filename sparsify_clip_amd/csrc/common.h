@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <math.h>
 #include "../../include/sparsify_hip.h"
@@ -34,6 +35,18 @@ int sc_set_error(int code, const char* fmt, ...);
         int rc__ = (expr);               \
         if (rc__ != 0) return rc__;      \
     } while (0)
+
+// A/B knobs of closed experiments (DESIGN.md section 5 lists each with what was measured): the shipped library answers every one of them with
+// its default; a -DSC_DEBUG_KNOBS build reads them from the environment again.  The knobs the test-suite exercises (SC_GEMM_NT, SC_GEMM_TN:
+// kernel variants that stay in the library for shapes the default kernels do not take) are read with plain getenv.
+static inline const char* sc_debug_env(const char* name) {
+#ifdef SC_DEBUG_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 static inline bool sc_aligned(const void* p, size_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
 static inline int64_t sc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -496,7 +496,7 @@ int bn_lpr(int64_t c) {
 // SC_CONV_SCALAR=<bit mask>: force the general (scalar) kernels - 1 im2col, 2 col2im, 4 average pools, 8 BatchNorm statistics, 16 BatchNorm
 // apply, 32 BatchNorm backward sums, 64 BatchNorm backward apply (A/B and bisection knob)
 bool vec_ok(int bit) {
-    static const int mask = [] { const char* e = getenv("SC_CONV_SCALAR"); return e ? atoi(e) : 0; }();
+    static const int mask = [] { const char* e = sc_debug_env("SC_CONV_SCALAR"); return e ? atoi(e) : 0; }();
     return !(mask & bit);
 }
 unsigned stream_grid(int64_t total) { return (unsigned)min((int64_t)4096, max((int64_t)1, sc_cdiv(total, 256))); }

@@ -1593,13 +1593,13 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
         p.tiles_m = (int)sc_cdiv(m, T_M); p.tiles_n = (int)sc_cdiv(n, T_N);
         const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
         static const int variant = [] { const char* e = getenv("SC_GEMM_NT"); return (e && e[0] == '2') ? 2 : 0; }();   // SC_GEMM_NT=2: 256x128 kernel everywhere (run once by the test-suite)
-        static const int big_min_n = [] { const char* e = getenv("SC_GEMM_NT_BIG_MINN"); return e ? atoi(e) : 512; }();   // A/B knob (1536: wide outputs only)
+        static const int big_min_n = [] { const char* e = sc_debug_env("SC_GEMM_NT_BIG_MINN"); return e ? atoi(e) : 512; }();   // A/B knob (1536: wide outputs only)
         if (variant == 0 && n >= big_min_n && m >= 4096) {
             // Tile-count quantisation: all tiles cost the same, so ceil(tiles / 256) rounds are paid even when the last one is
             // nearly empty (600 tiles = 2.34 -> 3 rounds at N = 768).  When it pays, only the row tiles that fill WHOLE rounds go
             // to the 256x256 kernel and the remaining rows are a second launch of the 256x128 kernel (half-size tiles: the
             // leftover becomes one well-filled round that costs ~0.55 of a 256x256 round).  SC_GEMM_NT_SPLIT=0 disables.
-            static const bool split_on = [] { const char* e = getenv("SC_GEMM_NT_SPLIT"); return !(e && e[0] == '0'); }();
+            static const bool split_on = [] { const char* e = sc_debug_env("SC_GEMM_NT_SPLIT"); return !(e && e[0] == '0'); }();
             const int64_t tn_b = sc_cdiv(n, B_N), tm_b = sc_cdiv(m, B_M);
             int64_t m_main = m;
             {
@@ -1612,8 +1612,8 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                     if (tm_main > 0 && rows_rem > 0 && (double)full + 0.55 * (double)rounds_rem < (double)(full + 1) - 0.1) m_main = tm_main * B_M;
                 }
             }
-            static const int g_m = [] { const char* e = getenv("SC_GEMM_NT_GROUP_M"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_M; }();   // A/B knobs
-            static const int g_n = [] { const char* e = getenv("SC_GEMM_NT_GROUP_N"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_N; }();
+            static const int g_m = [] { const char* e = sc_debug_env("SC_GEMM_NT_GROUP_M"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_M; }();   // A/B knobs
+            static const int g_n = [] { const char* e = sc_debug_env("SC_GEMM_NT_GROUP_N"); return e && atoi(e) > 0 ? atoi(e) : B_GROUP_N; }();
             p.group_m = g_m; p.group_n = g_n;
             p.half_tiles = 0; p.half_m0 = 0;
             // persistent kernel: whole tiles and one of the step's four epilogues; SC_GEMM_NT=b forces one tile per workgroup (A/B)
@@ -1652,12 +1652,12 @@ int sc_gemm_bf16_nt_launch(int64_t m, int64_t n, int64_t k, const void* a, int64
                 {
                     const int64_t rounds = (tm_all * tn_b) / G;
                     const int64_t tm_b2 = (rounds * G) / tn_b;      // row tiles that fill whole rounds
-                    static const bool split_on2 = [] { const char* e = getenv("SC_GEMM_NT_SPLIT"); return !(e && e[0] == '0'); }();
+                    static const bool split_on2 = [] { const char* e = sc_debug_env("SC_GEMM_NT_SPLIT"); return !(e && e[0] == '0'); }();
                     if (split_on2 && tm_b2 < tm_all &&
                         cost(tm_b2 * tn_b, ((tm_all - tm_b2) * 2 + tail) * tn_b) + 0.02 < cost(tm_all * tn_b, tail * tn_b))
                         tm_main = tm_b2;
                 }
-                static const bool tickets_on = [] { const char* e = getenv("SC_GEMM_TICKETS"); return !(e && e[0] == '0'); }();   // =0: fixed tile lists (A/B runs)
+                static const bool tickets_on = [] { const char* e = sc_debug_env("SC_GEMM_TICKETS"); return !(e && e[0] == '0'); }();   // =0: fixed tile lists (A/B runs)
                 if (!tickets_on || k < 3 * KSTEP) p.epi.tickets = nullptr;   // the ticket protocol needs three K-tiles
                 p.M = (int)m;
                 p.tiles_m = (int)tm_main; p.tiles_n = (int)tn_b;

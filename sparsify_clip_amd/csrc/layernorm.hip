@@ -275,7 +275,7 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
                                 int accumulate, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && gamma && dx, SC_ERR_ARG, "sc_layernorm_bwd: null argument");
     SC_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && width <= LN_MAX_CHUNKS * 256, SC_ERR_SHAPE, "sc_layernorm_bwd: bad width %lld", (long long)width);
-    static const int max_blocks = [] { const char* e = getenv("SC_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= RED_MAX_BLOCKS ? v : RED_MAX_BLOCKS; }();   // A/B knob
+    static const int max_blocks = [] { const char* e = sc_debug_env("SC_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= RED_MAX_BLOCKS ? v : RED_MAX_BLOCKS; }();   // A/B knob
     const int nblocks = (int)min((int64_t)max_blocks, sc_cdiv(rows, 4));
     const int nsum = dx_colsum ? 3 : 2;
     SC_REQUIRE(ws && ws_bytes >= (size_t)nblocks * nsum * width * sizeof(float), SC_ERR_WORKSPACE, "sc_layernorm_bwd: workspace too small");

@@ -32,7 +32,7 @@ namespace {
 // SC_LOSS_FUSED=0: the round-1 path (fp32 MFMA GEMMs on a materialised [B,B] matrix) for every shape (A/B; it stays the path of
 // batches that are not a multiple of 64 and of widths that are not a multiple of 128)
 bool fused_on() {
-    static const bool on = [] { const char* e = getenv("SC_LOSS_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = sc_debug_env("SC_LOSS_FUSED"); return !(e && e[0] == '0'); }();
     return on;
 }
 bool use_fused(int64_t b, int64_t e) { return fused_on() && sc_pair_supported(b, e); }

@@ -353,7 +353,7 @@ struct PairWs {      // carved from the caller's workspace
 
 static int pair_nsplit(int64_t b) {
     const int64_t it = b / PT;
-    static const int wgs = [] { const char* e = getenv("SC_PAIR_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // two workgroups per CU hide each other's barriers
+    static const int wgs = [] { const char* e = sc_debug_env("SC_PAIR_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();   // two workgroups per CU hide each other's barriers
     int64_t s = wgs / it;
     if (s < 1) s = 1;
     if (s > it) s = it;
@@ -484,7 +484,7 @@ int sc_pair_sparsify(const float* x, int64_t b, int64_t e, float grad_scale, flo
 // workspace layout as the square forms (the partial buffers of a rectangle never exceed those of the square).
 static int pair_nsplit_rows(int64_t bm, int64_t b) {
     const int64_t it = bm / PT, jt = b / PT;
-    static const int wgs = [] { const char* e = getenv("SC_PAIR_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    static const int wgs = [] { const char* e = sc_debug_env("SC_PAIR_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
     int64_t s = wgs / it;
     if (s < 1) s = 1;
     if (s > jt) s = jt;

@@ -64,28 +64,6 @@ def shard_bounds(global_batch: int, rank: int, world: int):
 
 
 _gather_bufs = {}
-_sim = {"world": 1, "fill": {}}
-
-
-def simulate_world(w: int):
-    """Bench-only: with no process group, make the gather return a [w*Bl, E] batch whose first Bl rows are this rank's and whose
-    other rows are fixed unit-norm filler, so that ONE GPU runs the loss head at the global batch of a w-rank job (what every rank
-    of that job computes).  No collective is simulated.  w = 1 switches it off."""
-    _sim["world"] = int(w)
-
-
-def _sim_gather(local: torch.Tensor, which: int):
-    bl, e = local.shape
-    w = _sim["world"]
-    key = (bl, e, w, which, str(local.device))
-    full = _sim["fill"].get(key)
-    if full is None:
-        g = torch.Generator(device="cpu").manual_seed(977 + which)
-        rows = torch.nn.functional.normalize(torch.randn(w * bl, e, generator=g), dim=-1)
-        full = _sim["fill"][key] = rows.to(local.device)
-    full[:bl].copy_(local)
-    return full
-
 
 
 def gather_send_buffer(bl: int, e: int, device):
@@ -103,8 +81,6 @@ def all_gather_embeddings(img_local: torch.Tensor, txt_local: torch.Tensor):
     """[Bl,E] x 2 -> [B,E] x 2 on every rank, rank-major: ONE collective on the fused [2, Bl, E] send buffer (received as
     [world, 2, Bl, E]), then one strided copy per modality into the contiguous [B,E] the loss head reads."""
     if not active():
-        if _sim["world"] > 1:
-            return _sim_gather(img_local, 0), _sim_gather(txt_local, 1)
         return img_local, txt_local
     bl, e = img_local.shape
     w = world_size()
@@ -123,17 +99,14 @@ def all_gather_embeddings(img_local: torch.Tensor, txt_local: torch.Tensor):
 
 
 def sharding():
-    """(world, rank) of the loss-head sharding: the process group's, or the bench's simulated world (rank 0), or (1, 0)."""
-    if active():
-        return world_size(), get_rank()
-    return (_sim["world"], 0) if _sim["world"] > 1 else (1, 0)
+    """(world, rank) of the loss-head sharding: the process group's, or (1, 0)."""
+    return (world_size(), get_rank()) if active() else (1, 0)
 
 
 def exchange_packets(packet: torch.Tensor) -> torch.Tensor:
     """The one collective of the sharded loss head: every rank's statistics packet [P] -> [world, P] (rank-major)."""
     if not active():
-        w = _sim["world"]
-        return packet.unsqueeze(0).expand(w, -1).contiguous() if w > 1 else packet.unsqueeze(0)     # bench only: filler = copies of rank 0's
+        return packet.unsqueeze(0)
     w = world_size()
     if dist.get_backend() == "gloo" and packet.is_cuda:   # rehearsal path only
         parts = [torch.empty_like(packet) for _ in range(w)]
@@ -153,7 +126,7 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
 def local_rows(full: torch.Tensor):
     """This rank's rows of a gathered [B,E] tensor (the backward of the gather needs no collective)."""
     if not active():
-        return full[: full.shape[0] // _sim["world"]].contiguous() if _sim["world"] > 1 else full
+        return full
     a, b = shard_bounds(full.shape[0], get_rank(), world_size())
     return full[a:b].contiguous()
 

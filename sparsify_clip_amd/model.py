@@ -513,8 +513,7 @@ class ClipModel:
         if self._side is None:
             self._side = {}
         if tower.kind not in self._side:
-            prio = -1 if os.environ.get("SC_STREAM_PRIO", "") == "s" else 0
-            self._side[tower.kind] = (torch.cuda.Stream(device=self.device, priority=prio), [torch.cuda.Event(), torch.cuda.Event()])
+            self._side[tower.kind] = (torch.cuda.Stream(device=self.device), [torch.cuda.Event(), torch.cuda.Event()])
         side, side_done = self._side[tower.kind]
         n = dx.numel()
         dx_t = [self._scratch[f"bwd.{tower.kind}.dx_t.{k}"][:n] for k in range(3)]

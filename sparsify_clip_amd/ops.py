@@ -175,8 +175,7 @@ def sparsify_fwd_bwd(x, grad_scale=1.0, need_grad=True):
 # ---- row-block ("sharded") forms: the rank owns rows [row0, row0 + bm) of the gathered batch (include/sparsify_hip.h)
 def loss_rows_supported(b, e, row0, bm) -> bool:
     """Shapes the row-block loss head takes (otherwise the caller evaluates the replicated loss head)."""
-    return b % 64 == 0 and b >= 128 and e % 128 == 0 and 128 <= e <= 1024 and row0 % 64 == 0 and bm % 64 == 0 and bm >= 64 and row0 + bm <= b \
-        and os.environ.get("SC_LOSS_FUSED", "1") != "0"
+    return b % 64 == 0 and b >= 128 and e % 128 == 0 and 128 <= e <= 1024 and row0 % 64 == 0 and bm % 64 == 0 and bm >= 64 and row0 + bm <= b
 
 
 def contrastive_rows_stats(img, txt, row0, bm, temperature):
@@ -537,7 +536,7 @@ def bn_apply(x, mean, rstd, gamma, beta, relu, res=None, halo=None):
 
 def bn_mask_from_x(c) -> bool:
     """Channel counts for which the BatchNorm backward can recompute the ReLU mask from x (y = None) instead of reading the stored output."""
-    if c % 4 or os.environ.get("SC_CONV_SCALAR", "0") != "0":
+    if c % 4:
         return False
     chunk = c if c <= 1024 else 1024
     lpr = chunk // 4

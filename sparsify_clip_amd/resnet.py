@@ -219,12 +219,30 @@ class ResNetVisual:
         gamma, beta = m.param(cv.bn + ".weight"), m.param(cv.bn + ".bias")
         if relu and not want_dres and (y is None or ops.bn_mask_from_x(cv.cout)):
             y = None         # no residual entered this BatchNorm: the ReLU mask is recomputed from z, one tensor less to read in both passes
-        sums = ops.bn_bwd_stats(dy, y, z, mean, rstd, relu, gamma, beta)
+        sums = ops.bn_bwd_stats(dy, y, z, mean, rstd, relu, gamma, beta)      # [2 C]: sum g, sum g xhat over this rank's rows
         world = D.world_size() if D.active() else 1
+        g_w, g_b = m.grad(cv.bn + ".weight"), m.grad(cv.bn + ".bias")
         if world > 1:
+            # The input gradient needs the WHOLE batch's sums; the affine parameters' gradients must stay this rank's share, because the
+            # bucket all-reduce adds the ranks' gradient buffers afterwards (rounds 1-2 wrote the all-reduced sums into them: d gamma and
+            # d beta came out `world` times too large under data parallelism - found by the gradient-level check of tests/test_gpu_dp.py).
+            c = cv.cout
+            if acc:
+                ops.axpy_(g_b, 1.0, sums[:c])
+                ops.axpy_(g_w, 1.0, sums[c:])
+            else:
+                g_b.copy_(sums[:c])
+                g_w.copy_(sums[c:])
             D.all_reduce_sum_(sums)
-        return ops.bn_bwd_apply(dy, y, z, mean, rstd, gamma, sums, rows * world, relu, m.grad(cv.bn + ".weight"), m.grad(cv.bn + ".bias"), acc,
+            g_w = g_b = self._bn_grad_sink(c, sums.device)      # the kernel's own (whole-batch) parameter sums go nowhere
+        return ops.bn_bwd_apply(dy, y, z, mean, rstd, gamma, sums, rows * world, relu, g_w, g_b, False if world > 1 else acc,
                                 want_dres, beta=beta, halo=halo)
+
+    def _bn_grad_sink(self, c, device):
+        sink = getattr(self, "_sink", None)
+        if sink is None or sink.numel() < c or sink.device != device:
+            sink = self._sink = torch.empty(max(c, 2048), dtype=torch.float32, device=device)
+        return sink[:c]
 
     def _conv_bwd(self, cv, dz, x_in, batch, h, w, acc, need_dx=True, images=None, resid=None):
         """dz: gradient of the convolution output rows; x_in: the convolution's input rows (or images).  Writes the weight gradient;

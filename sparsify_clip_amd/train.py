@@ -79,6 +79,7 @@ class Trainer:
         self.beta, self.alpha = 0.0, 0.0    # :743-744
         self.pending_logs = []
         self.text_stream = None
+        self.on_gradients = None    # optional callable(trainer): runs when the (all-reduced) gradients are final, in front of the optimiser step
 
     def step(self, images, captions, text_len=None):
         """text_len (optional): the batch's longest caption in tokens (EOT included), known on the host.  With `text_trim: True` in the
@@ -96,8 +97,7 @@ class Trainer:
         # kernels (LayerNorm, attention, embedding) overlap the image tower's GEMMs and vice versa
         main = torch.cuda.current_stream()
         if self.text_stream is None:
-            # SC_STREAM_PRIO=t/s: high priority for the text tower's stream / for the weight-gradient side streams (A/B knob; default: equal)
-            self.text_stream = torch.cuda.Stream(device=self.device, priority=-1 if os.environ.get("SC_STREAM_PRIO", "") == "t" else 0)
+            self.text_stream = torch.cuda.Stream(device=self.device)      # equal priority (a high-priority text / weight-gradient stream measured worse, round 2)
         self.text_stream.wait_stream(main)
         with torch.cuda.stream(self.text_stream):
             txt_e = m.text_forward(tokens, seq_len=text_len)                       # :769
@@ -139,6 +139,8 @@ class Trainer:
         if self.learnable_t and res.d_temp is not None:
             self.temperature.grad = res.d_temp.detach().cpu().reshape(())
         self.sync.wait_all()
+        if self.on_gradients is not None:
+            self.on_gradients(self)
         self.optimizer.step()                                                      # :966
         self.scheduler.step()                                                      # :969
         if len(self.pending_logs) >= cfg.get("log_every", 10):
@@ -252,6 +254,8 @@ class Trainer:
         if self.learnable_t and res.d_temp is not None:
             self.temperature.grad = res.d_temp.detach().cpu().reshape(())
         self.sync.wait_all()
+        if self.on_gradients is not None:
+            self.on_gradients(self)
         self.optimizer.step()
         self.scheduler.step()
         if len(self.pending_logs) >= cfg.get("log_every", 10):

@@ -289,3 +289,22 @@ def test_host_gather_rows_native():
         LIB.call("sc_host_gather_rows", n, src, stride.ctypes.data, rows.ctypes.data, row_bytes.ctypes.data, dst.ctypes.data, offset.ctypes.data,
                  want.size - 1, 2)
     LIB.call("sc_host_gather_rows", 0, None, None, None, None, None, None, 0, 4)      # an empty batch is a no-op
+
+
+def test_bench_simulated_world_patches_and_restores_dist():
+    """bench.py's N = 1 'one rank of a w-GPU job' measurement patches the four meeting points of the trainer with sparsify_clip_amd.dist
+    for its duration only (the simulation does not live in the product module)."""
+    import bench
+    from sparsify_clip_amd import dist as D
+    before = (D.all_gather_embeddings, D.sharding, D.exchange_packets, D.local_rows)
+    img, txt = torch.nn.functional.normalize(torch.randn(4, 8), dim=-1), torch.nn.functional.normalize(torch.randn(4, 8), dim=-1)
+    assert D.sharding() == (1, 0) and D.all_gather_embeddings(img, txt)[0] is img
+    with bench.simulated_world(4):
+        gi, gt = D.all_gather_embeddings(img, txt)
+        assert gi.shape == (16, 8) and torch.equal(gi[:4], img) and torch.equal(gt[:4], txt)
+        assert torch.allclose(gi.norm(dim=-1), torch.ones(16), atol=1e-6)
+        assert D.sharding() == (4, 0)
+        assert D.exchange_packets(torch.arange(3.0)).shape == (4, 3)
+        assert torch.equal(D.local_rows(gi), img)
+    assert (D.all_gather_embeddings, D.sharding, D.exchange_packets, D.local_rows) == before
+    assert D.sharding() == (1, 0) and D.local_rows(img) is img
