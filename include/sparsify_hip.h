@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_SHAPE = -2, SC_ERR_DTYPE = -3, SC_ERR_ALIGN = -4,
        SC_ERR_WORKSPACE = -5, SC_ERR_NO_DEVICE = -6 };
@@ -198,6 +198,20 @@ int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype,
  * pass over d_qkv (ws >= 4096*3*width*4 bytes). */
 int sc_attention_bwd_colsum(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
                             int64_t heads, int causal, float* colsum, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same pair in the flash-attention form: the forward also leaves the softmax statistics of every query row,
+ *   lse[(b * heads + h) * seq + i] = -(m_i log2 e + log2 l_i)   (fp32 [batch * heads * seq];  P_ij = 2^(s_ij / 8 * log2 e + lse_i)),
+ * and the backward takes them together with the forward's output `out` (delta_i = dO_i . O_i), so it needs neither the row maxima nor
+ * the row sums again: on long sequences (bf16, 80 < seq <= 272: one workgroup per head, scores recomputed per key tile) pass 1 of the
+ * backward is one sweep over the keys instead of three.  sc_attention_uses_stats(dtype, seq) != 0 says whether the forward writes
+ * `lse` for a shape (otherwise it is left untouched and the backward ignores it: both calls then behave as the plain pair above);
+ * colsum may be NULL (no bias gradient; ws unused then).  Replaces nn.MultiheadAttention's core behind reference
+ * sparsify_clip.py:768-769 for ViT-L/14's 257-token image sequences (BASELINE config 5). */
+int sc_attention_uses_stats(int dtype, int64_t seq);
+int sc_attention_fwd_stats(const void* qkv, void* out, float* lse, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads,
+                           int causal, void* stream);
+int sc_attention_bwd_stats(const void* qkv, const void* out, const float* lse, const void* d_out, void* d_qkv, int dtype, int64_t batch,
+                           int64_t seq, int64_t width, int64_t heads, int causal, float* colsum, int accumulate, void* ws, size_t ws_bytes,
+                           void* stream);
 /* column sums: out[n] (+)= sum_r x[r][n]  (bias gradients).  ws >= 1024*n floats */
 int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate,
               void* ws, size_t ws_bytes, void* stream);
@@ -272,6 +286,9 @@ typedef struct sc_block_desc {
     /* optional: tile tickets for the NT GEMMs the call enqueues on `stream` (sc_gemm_epilogue.tile_tickets: 64 zeroed, 64-byte
      * aligned bytes); descriptors whose calls are enqueued on one stream may share them.  NULL = fixed tile lists. */
     void* tile_tickets;
+    /* optional (ABI 5): fp32 [batch * heads * seq] softmax statistics of the block's attention, written by sc_block_fwd and read by
+     * sc_block_bwd when sc_attention_uses_stats(dtype, seq) (sc_attention_fwd_stats / _bwd_stats); NULL = the plain attention pair */
+    float* attn_lse;
 } sc_block_desc;
 
 size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype);

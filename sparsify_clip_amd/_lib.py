@@ -46,7 +46,7 @@ class BlockDesc(ctypes.Structure):
                 [("accumulate", ctypes.c_int32), ("b_fc2_done", ctypes.c_int32)] +
                 [(n, ctypes.c_void_p) for n in _BLOCK_PTRS_2] +
                 [("ws_bytes", ctypes.c_size_t), ("g_below_b_fc2", ctypes.c_void_p), ("ws_side", ctypes.c_void_p), ("ws_side_bytes", ctypes.c_size_t),
-                 ("events", ctypes.c_void_p * 4), ("tile_tickets", ctypes.c_void_p)])
+                 ("events", ctypes.c_void_p * 4), ("tile_tickets", ctypes.c_void_p), ("attn_lse", ctypes.c_void_p)])
 
 
 _CTYPES = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,

@@ -11,9 +11,10 @@
 int sc_attention_mfma_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
 int sc_attention_mfma_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                           float* cs_part, hipStream_t st);
-int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st);
+int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st, float* lse);
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                          float* cs_part, hipStream_t st);
+                          float* cs_part, hipStream_t st, const void* fwd_out, const float* lse);
+bool sc_attention_long_uses_stats(int64_t seq);
 
 int sc_colsum_reduce(const float* partial, int nslab, int64_t n, float* out, int accumulate, hipStream_t st);
 extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
@@ -277,14 +278,28 @@ int sc_attention_f32_composed_bwd(const float* qkv, const float* d_out, float* d
     return SC_OK;
 }
 
+namespace {
+int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, void* stream);
+}
 extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
                                 void* stream) {
+    return attention_fwd_impl(qkv, out, nullptr, dtype, batch, seq, width, heads, causal, stream);
+}
+extern "C" int sc_attention_uses_stats(int dtype, int64_t seq) {
+    return dtype == SC_BF16 && use_mfma() && !short_recompute() && sc_attention_long_uses_stats(seq) ? 1 : 0;
+}
+extern "C" int sc_attention_fwd_stats(const void* qkv, void* out, float* lse, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads,
+                                      int causal, void* stream) {
+    return attention_fwd_impl(qkv, out, lse && sc_attention_uses_stats(dtype, seq) ? lse : nullptr, dtype, batch, seq, width, heads, causal, stream);
+}
+namespace {
+int attention_fwd_impl(const void* qkv, void* out, float* lse, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, void* stream) {
     SC_TRY(check("sc_attention_fwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && out, SC_ERR_ARG, "sc_attention_fwd: null argument");
     if (dtype == SC_BF16 && use_mfma()) {
         // forward, seq <= 80: one wave per head measured faster (81 / 86 us vs 85 / 112 us at the step's two shapes)
         int rc = short_recompute() ? 1 : sc_attention_mfma_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
-        if (rc == 1) rc = sc_attention_long_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream);
+        if (rc == 1) rc = sc_attention_long_fwd(qkv, out, batch, seq, width, heads, causal, (hipStream_t)stream, lse);
         if (rc != 1) return rc;
     }
     const size_t lds = ((size_t)3 * seq * HDP + 4 * 128) * sizeof(float);
@@ -302,11 +317,12 @@ extern "C" int sc_attention_fwd(const void* qkv, void* out, int dtype, int64_t b
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
+}  // namespace
 
 namespace {
 // cs_part != null: the MFMA kernels also write [batch][3 W] column sums of d_qkv per image; *cs_done tells whether they did
 int attention_bwd_impl(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                       float* cs_part, bool* cs_done, void* stream) {
+                       float* cs_part, bool* cs_done, void* stream, const void* fwd_out = nullptr, const float* lse = nullptr) {
     if (cs_done) *cs_done = false;
     SC_TRY(check("sc_attention_bwd", dtype, batch, seq, width, heads));
     SC_REQUIRE(qkv && d_out && d_qkv, SC_ERR_ARG, "sc_attention_bwd: null argument");
@@ -314,7 +330,7 @@ int attention_bwd_impl(const void* qkv, const void* d_out, void* d_qkv, int dtyp
         // backward, seq <= 80: two waves per head on shared LDS images (208 us at S = 77, 242 us at S = 50; one wave per head: 286 / 303 us,
         // one workgroup per head: 341 / 262 us)
         int rc = short_recompute() ? 1 : sc_attention_mfma_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream);
-        if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream);
+        if (rc == 1) rc = sc_attention_long_bwd(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, (hipStream_t)stream, fwd_out, lse);
         if (rc != 1) {
             if (cs_done) *cs_done = rc == SC_OK && cs_part != nullptr;
             return rc;
@@ -341,6 +357,20 @@ int attention_bwd_impl(const void* qkv, const void* d_out, void* d_qkv, int dtyp
 extern "C" int sc_attention_bwd(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,
                                 int64_t heads, int causal, void* stream) {
     return attention_bwd_impl(qkv, d_out, d_qkv, dtype, batch, seq, width, heads, causal, nullptr, nullptr, stream);
+}
+
+extern "C" int sc_attention_bwd_stats(const void* qkv, const void* out, const float* lse, const void* d_out, void* d_qkv, int dtype, int64_t batch,
+                                      int64_t seq, int64_t width, int64_t heads, int causal, float* colsum, int accumulate, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    const bool stats = out && lse && sc_attention_uses_stats(dtype, seq);
+    if (!colsum) return attention_bwd_impl(qkv, d_out, d_qkv, dtype, batch, seq, width, heads, causal, nullptr, nullptr, stream, stats ? out : nullptr, stats ? lse : nullptr);
+    SC_REQUIRE(ws, SC_ERR_ARG, "sc_attention_bwd_stats: colsum needs a workspace");
+    const int64_t n = 3 * width;
+    float* part = (ws_bytes >= (size_t)batch * n * sizeof(float) && sc_aligned(ws, 16)) ? (float*)ws : nullptr;
+    bool fused = false;
+    SC_TRY(attention_bwd_impl(qkv, d_out, d_qkv, dtype, batch, seq, width, heads, causal, part, &fused, stream, stats ? out : nullptr, stats ? lse : nullptr));
+    if (fused) return sc_colsum_reduce(part, (int)batch, n, colsum, accumulate, (hipStream_t)stream);
+    return sc_colsum(d_qkv, dtype, batch * seq, n, n, colsum, accumulate, ws, ws_bytes, stream);
 }
 
 extern "C" int sc_attention_bwd_colsum(const void* qkv, const void* d_out, void* d_qkv, int dtype, int64_t batch, int64_t seq, int64_t width,

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(64 * NW, NT <= 8 ? 2 : 1) void attn_bwd_long_kernel
 // score product recomputed) instead of NT score tiles held in registers and fully unrolled loops: ~100 VGPRs, 8 waves per
 // workgroup and two workgroups (78 KiB of K / V images each) per CU.
 template <int NT, bool CAUSAL, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, float scale) {
+__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, float scale,
+                                                                    float* lse /* [batch * H * S] or null: -(m log2 e + log2 l) per query row */) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t
             bf16_t* op = out + ((int64_t)b * S + i) * W + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(op + 16 * dt, o[dt] * inv);
+            if (lse && g == 0) lse[(int64_t)blockIdx.x * S + i] = __builtin_amdgcn_logf(inv) - m * 1.4426950408889634f;   // P_ij = 2^(s_ij scale log2 e + lse_i)
         }
     }
 }
@@ -366,9 +368,15 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t
 // three times - row max; row sum and delta = sum_j p_ij dp_ij; dQ - recomputing the two 16x16 MFMA products per key tile each
 // time (MFMA work is negligible here).  V is staged in LDS as a fourth image (4 x 272 x 144 B + statistics = 156 KiB), so
 // every fragment comes from LDS and the register budget allows NW = 16 waves per workgroup (4 per SIMD).
-template <int NT, bool CAUSAL, int NW>
+//
+// STATS = true (round 3, the flash-attention form): the forward hands over lse_i = -(m_i log2 e + log2 l_i) and its output O, so
+// P_ij = 2^(s_ij c + lse_i) needs no row maximum and no row sum, and delta_i = sum_j p_ij dp_ij = dO_i . O_i is a 64-term dot product per
+// query row.  Pass 1 is then ONE sweep over the key tiles (scores, dP, dS, dQ) instead of three, pass 2 reads lse / delta from LDS; masks
+// are applied on the tiles that contain a masked pair only, rows beyond the sequence carry lse = -inf (P = 0).  ViT-L/14 (S = 257, 16
+// heads, local batch 512): 2.12 -> see profiles/r03_attention_l14_times.txt.
+template <int NT, bool CAUSAL, int NW, bool STATS>
 __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale,
-                                                                         float* cs_part /* [batch][3 W] or null */) {
+                                                                         float* cs_part /* [batch][3 W] or null */, const bf16_t* fwd_out, const float* lse) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;
@@ -398,7 +406,68 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const b
     f32x4 csq[4], csk[4], csv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) csq[dt] = csk[dt] = csv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c = scale * 1.4426950408889634f;   // exp(x scale) = 2^(x c)
     // ---------------- pass 1: lane = query row i
+    if constexpr (STATS) {
+        for (int it = wave; it < n_t; it += NW) {
+            const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
+            const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
+            const int i = it * 16 + c16;
+            const bool live = i < S;
+            const int jt_end = CAUSAL ? min(n_t, it + 1) : n_t;
+            // delta_i = dO_i . O_i: this lane's 16 of the 64 head dimensions (the fragment's own), summed over the four lane groups
+            const bf16x8 o0 = row_frag_global(fwd_out + (int64_t)b * S * W + h * HD, W, it, 0, lane, S),
+                         o1 = row_frag_global(fwd_out + (int64_t)b * S * W + h * HD, W, it, 1, lane, S);
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                dot += bf16_to_f32((bf16_t)g0[e]) * bf16_to_f32((bf16_t)o0[e]) + bf16_to_f32((bf16_t)g1[e]) * bf16_to_f32((bf16_t)o1[e]);
+            const float delta = group_sum(dot);        // rows beyond the sequence: their dO rows are zero in the LDS image
+            const float ei = live ? lse[(int64_t)blockIdx.x * S + i] : -INFINITY;
+            const float nds = -delta * scale;
+            if (g == 0) { st_m[i] = ei; st_dl[i] = live ? nds : 0.f; }
+            f32x4 dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < KS; ++s) {
+                if (2 * s >= jt_end) break;
+                f32x4 ds[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int jt = 2 * s + u;
+                    ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (jt >= jt_end) continue;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
+                    a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+                    d = MFMA16(row_frag_lds(Vs, jt, 0, lane), g0, d);
+                    d = MFMA16(row_frag_lds(Vs, jt, 1, lane), g1, d);
+                    const bool edge = jt * 16 + 16 > S || (CAUSAL && jt == it);   // the only tiles with masked pairs (wave-uniform)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], c, ei));
+                        if (edge) {
+                            const int j = jt * 16 + 4 * g + r;
+                            p = (j < S && (!CAUSAL || j <= i)) ? p : 0.f;
+                        }
+                        ds[u][r] = p * __builtin_fmaf(d[r], scale, nds);
+                    }
+                }
+                const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+                const bool hi_valid = !(ODD && s == KS - 1);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 kt = hi_valid ? tr_frag<true>(Ks, s, 16 * dt, lane) : tr_frag<false>(Ks, s, 16 * dt, lane);
+                    dq[dt] = MFMA16(kt, dsf, dq[dt]);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
+            }
+            if (cs_part) cs_add(csq, dq, live);
+        }
+    } else
     for (int it = wave; it < n_t; it += NW) {
         const bf16x8 q0 = row_frag_lds(Qs, it, 0, lane), q1 = row_frag_lds(Qs, it, 1, lane);
         const bf16x8 g0 = row_frag_lds(Os, it, 0, lane), g1 = row_frag_lds(Os, it, 1, lane);
@@ -503,18 +572,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const b
                 a = MFMA16(row_frag_lds(Qs, it, 1, lane), k1, a);
                 d = MFMA16(row_frag_lds(Os, it, 0, lane), v0, d);
                 d = MFMA16(row_frag_lds(Os, it, 1, lane), v1, d);
-                const f32x4 mm = *(const f32x4*)(st_m + it * 16 + 4 * g), il = *(const f32x4*)(st_il + it * 16 + 4 * g),
-                            dl = *(const f32x4*)(st_dl + it * 16 + 4 * g);
+                const f32x4 mm = *(const f32x4*)(st_m + it * 16 + 4 * g), dl = *(const f32x4*)(st_dl + it * 16 + 4 * g);
+                if constexpr (STATS) {   // mm = lse (-inf for rows beyond the sequence: p = 0, their dO rows are zero), dl = -scale delta;
+                                         // keys beyond the sequence only produce lanes that are never stored: mask the diagonal tile only
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = it * 16 + 4 * g + r;
-                    const bool ok = i < S && j < S && (!CAUSAL || j <= i);
-                    const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
-                    pt[u][r] = p;
-                    dst[u][r] = ok ? p * (d[r] - dl[r]) * scale : 0.f;   // not 0 * (d - dl): d, dl of a masked pair need not be finite
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], c, mm[r]));
+                        if (CAUSAL && it == jt) p = (j <= it * 16 + 4 * g + r) ? p : 0.f;
+                        pt[u][r] = p;
+                        dst[u][r] = p * __builtin_fmaf(d[r], scale, dl[r]);
+                    }
+                } else {
+                    const f32x4 il = *(const f32x4*)(st_il + it * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = it * 16 + 4 * g + r;
+                        const bool ok = i < S && j < S && (!CAUSAL || j <= i);
+                        const float p = ok ? __expf(a[r] * scale - mm[r]) * il[r] : 0.f;
+                        pt[u][r] = p;
+                        dst[u][r] = ok ? p * (d[r] - dl[r]) * scale : 0.f;   // not 0 * (d - dl): d, dl of a masked pair need not be finite
+                    }
                 }
             }
             if (CAUSAL && 2 * s + 1 < jt) continue;
+            if (2 * s >= n_t) continue;
             const bf16x8 pf = pack_frag(pt[0], pt[1]), dsf = pack_frag(dst[0], dst[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -600,15 +681,15 @@ int launch_bwd_block(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
 }
 
 template <int NT, int NW>
-int launch_fwd_long2(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+int launch_fwd_long2(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st, float* lse = nullptr) {
     const size_t lds = (size_t)2 * NT * 16 * LDR * sizeof(bf16_t);
     const dim3 grid((unsigned)(batch * heads));
     if (causal) {
         SC_TRY(reserve_lds(attn_fwd_long2_kernel<NT, true, NW>, lds));
-        hipLaunchKernelGGL((attn_fwd_long2_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+        hipLaunchKernelGGL((attn_fwd_long2_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f, lse);
     } else {
         SC_TRY(reserve_lds(attn_fwd_long2_kernel<NT, false, NW>, lds));
-        hipLaunchKernelGGL((attn_fwd_long2_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f);
+        hipLaunchKernelGGL((attn_fwd_long2_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (bf16_t*)out, (int)seq, (int)width, (int)heads, 0.125f, lse);
     }
     SC_CHECK_LAUNCH();
     return SC_OK;
@@ -616,18 +697,19 @@ int launch_fwd_long2(const void* qkv, void* out, int64_t batch, int64_t seq, int
 
 template <int NT, int NW>
 int launch_bwd_long2(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, float* cs_part,
-                     hipStream_t st) {
+                     hipStream_t st, const void* fwd_out = nullptr, const float* lse = nullptr) {
     const size_t lds = ((size_t)4 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)3 * NT * 16 * sizeof(float);
     const dim3 grid((unsigned)(batch * heads));
-    if (causal) {
-        SC_TRY(reserve_lds(attn_bwd_long2_kernel<NT, true, NW>, lds));
-        hipLaunchKernelGGL((attn_bwd_long2_kernel<NT, true, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
-                           (int)width, (int)heads, 0.125f, cs_part);
-    } else {
-        SC_TRY(reserve_lds(attn_bwd_long2_kernel<NT, false, NW>, lds));
-        hipLaunchKernelGGL((attn_bwd_long2_kernel<NT, false, NW>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq,
-                           (int)width, (int)heads, 0.125f, cs_part);
-    }
+#define BWD_L2(C, ST)                                                                                                                                   \
+    do {                                                                                                                                                \
+        SC_TRY(reserve_lds(attn_bwd_long2_kernel<NT, C, NW, ST>, lds));                                                                                 \
+        hipLaunchKernelGGL((attn_bwd_long2_kernel<NT, C, NW, ST>), grid, dim3(64 * NW), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, \
+                           (int)seq, (int)width, (int)heads, 0.125f, cs_part, (const bf16_t*)fwd_out, lse);                                             \
+    } while (0)
+    const bool stats = fwd_out != nullptr && lse != nullptr;
+    if (causal) { if (stats) BWD_L2(true, true); else BWD_L2(true, false); }
+    else { if (stats) BWD_L2(false, true); else BWD_L2(false, false); }
+#undef BWD_L2
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
@@ -639,7 +721,14 @@ int launch_bwd_long2(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
 // workgroup: ~28 KiB per head at seq <= 64, so five workgroups = 20 waves fit a CU, where the one-wave-per-head kernels of
 // attention_mfma.hip (private images, 110 KiB per 4-wave workgroup) are held to ONE wave per SIMD by LDS capacity.
 // Returns 1 when the shape is not covered.
-int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st) {
+// lse (fp32 [batch * heads * seq]) is written by the kernel the long sequences take (80 < seq <= 272) and left alone otherwise:
+// sc_attention_long_uses_stats says which, so that the backward knows whether the statistics exist
+bool sc_attention_long_uses_stats(int64_t seq) {
+    static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();
+    return seq > 80 && seq <= NT_LONG * 16 && !old_long;
+}
+
+int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, hipStream_t st, float* lse) {
     if (seq > NT_LONG * 16) return 1;
     static const bool short2 = [] { const char* e = sc_debug_env("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();
     if (short2 && seq <= 64) return launch_fwd_long2<4, 4>(qkv, out, batch, seq, width, heads, causal, st);
@@ -648,11 +737,11 @@ int sc_attention_long_fwd(const void* qkv, void* out, int64_t batch, int64_t seq
     if (seq <= 80) return launch_fwd_block<5, 5>(qkv, out, batch, seq, width, heads, causal, st);
     static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variants (A/B)
     if (old_long) return launch_fwd_block<NT_LONG, 4>(qkv, out, batch, seq, width, heads, causal, st);
-    return launch_fwd_long2<NT_LONG, 8>(qkv, out, batch, seq, width, heads, causal, st);
+    return launch_fwd_long2<NT_LONG, 8>(qkv, out, batch, seq, width, heads, causal, st, lse);
 }
 
 int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal,
-                          float* cs_part, hipStream_t st) {
+                          float* cs_part, hipStream_t st, const void* fwd_out, const float* lse) {
     if (seq > NT_LONG * 16) return 1;
     static const bool short2 = [] { const char* e = sc_debug_env("SC_ATTENTION_SHORT"); return e && e[0] == '2'; }();   // =2: recompute kernels for short sequences too (A/B)
     if (short2 && seq <= 64) return launch_bwd_long2<4, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
@@ -664,5 +753,6 @@ int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64
     // (6.1 ms per layer at local batch 512): a recompute-per-key-tile formulation is the next step for that model.
     static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variant (A/B)
     if (old_long) return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
-    return launch_bwd_long2<NT_LONG, 8>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
+    const bool stats = fwd_out && lse && sc_attention_long_uses_stats(seq);
+    return launch_bwd_long2<NT_LONG, 8>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st, stats ? fwd_out : nullptr, stats ? lse : nullptr);
 }

@@ -117,7 +117,7 @@ extern "C" int sc_block_fwd(const sc_block_desc* d, void* stream) {
     if (dt == SC_F32 && d->seq > 128)   // fp32 parity path of long sequences: composed from the fp32 GEMM, needs a workspace
         SC_TRY(sc_attention_f32_composed_fwd((const float*)d->qkv, (float*)d->attn_out, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, (hipStream_t)stream));
     else
-        SC_TRY(sc_attention_fwd(d->qkv, d->attn_out, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
+        SC_TRY(sc_attention_fwd_stats(d->qkv, d->attn_out, d->attn_lse, dt, d->batch, d->seq, W, d->heads, d->causal, stream));   // lse NULL / shapes without statistics: the plain forward
     // out_proj (+bias) + residual -> fp32 x_mid
     e = epi_plain();
     e.bias = d->b_o; e.resid = d->x_in; e.resid_dtype = SC_F32; e.ld_aux = W;
@@ -240,8 +240,8 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     // in_proj's bias gradient = column sums of d_qkv: taken by the attention backward while dq / dk / dv are in registers
     if (dt == SC_F32 && !sc_attention_f32_bwd_fits_lds(d->seq))   // the one-workgroup-per-head fp32 backward holds S x S scores and dP in LDS
         SC_TRY(sc_attention_f32_composed_bwd((const float*)d->qkv, (const float*)d->d_attn, (float*)d->d_qkv, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, st));
-    else if (fcs) SC_TRY(sc_attention_bwd_colsum(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, d->g_b_qkv, acc, d->ws, d->ws_bytes, stream));
-    else SC_TRY(sc_attention_bwd(d->qkv, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, stream));
+    else SC_TRY(sc_attention_bwd_stats(d->qkv, d->attn_out, d->attn_lse, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, fcs ? d->g_b_qkv : nullptr, acc,
+                                       d->ws, d->ws_bytes, stream));
     SC_TRY(publish());
     if (grouped) {   // dW of c_proj, c_fc, out_proj, in_proj: every operand (g, h_act, d_h, ln2_out, gm, attn_out, d_qkv, ln1_out) is final here
         const int64_t pm[4] = {W, MLP, W, 3 * W}, pn[4] = {MLP, W, W, W};

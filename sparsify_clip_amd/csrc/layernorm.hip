@@ -270,19 +270,45 @@ extern "C" int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, con
     return SC_OK;
 }
 
+// workgroups of layernorm_bwd_kernel<T, NSUM, CH> the device holds at once (occupancy query per instantiation and LDS size, cached)
+namespace {
+template <typename T, int NS, int C>
+int ln_bwd_resident_of(size_t lds_bytes) {
+    static size_t seen_lds = (size_t)-1;
+    static int seen = 0;
+    if (seen_lds != lds_bytes) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layernorm_bwd_kernel<T, NS, C>, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        seen = per_cu * cus;
+        seen_lds = lds_bytes;
+    }
+    return seen;
+}
+int ln_bwd_resident(int dtype, int nsum, int ch, size_t lds_bytes) {
+#define LNR(T, NS) (ch == 2 ? ln_bwd_resident_of<T, NS, 2>(lds_bytes) : ch == 3 ? ln_bwd_resident_of<T, NS, 3>(lds_bytes) : ch == 4 ? ln_bwd_resident_of<T, NS, 4>(lds_bytes) : ln_bwd_resident_of<T, NS, 8>(lds_bytes))
+    if (dtype == SC_BF16) return nsum == 3 ? LNR(bf16_t, 3) : LNR(bf16_t, 2);
+    return nsum == 3 ? LNR(float, 3) : LNR(float, 2);
+#undef LNR
+}
+}  // namespace
+
 extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
                                 int64_t width, const float* dres, float* dx, void* dx_cast, float* dgamma, float* dbeta, float* dx_colsum,
                                 int accumulate, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && gamma && dx, SC_ERR_ARG, "sc_layernorm_bwd: null argument");
     SC_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && width <= LN_MAX_CHUNKS * 256, SC_ERR_SHAPE, "sc_layernorm_bwd: bad width %lld", (long long)width);
-    static const int max_blocks = [] { const char* e = sc_debug_env("SC_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= RED_MAX_BLOCKS ? v : RED_MAX_BLOCKS; }();   // A/B knob
-    const int nblocks = (int)min((int64_t)max_blocks, sc_cdiv(rows, 4));
     const int nsum = dx_colsum ? 3 : 2;
+    const size_t lds_bytes = (size_t)4 * nsum * width * sizeof(float);
+    const int ch = width <= 512 ? 2 : width <= 768 ? 3 : width <= 1024 ? 4 : 8;
+    // One ROUND of workgroups: the rows are dealt to the blocks statically, so a grid larger than what the chip holds at once ends on a
+    // partly filled second round (width 1024: 150 VGPRs = 3 blocks per CU, 1024 blocks = 1.33 rounds - the ViT-L/14 LayerNorm backward ran
+    // at 3.9 TB/s of its bytes where the narrower ones reach 5.1-5.3)
+    const int resident = ln_bwd_resident(dtype, nsum, ch, lds_bytes);
+    const int nblocks = (int)min((int64_t)min(RED_MAX_BLOCKS, resident), sc_cdiv(rows, 4));
     SC_REQUIRE(ws && ws_bytes >= (size_t)nblocks * nsum * width * sizeof(float), SC_ERR_WORKSPACE, "sc_layernorm_bwd: workspace too small");
     SC_REQUIRE(sc_aligned(ws, 16) && sc_aligned(x, 16) && sc_aligned(dx, 16) && sc_aligned(dy, 8), SC_ERR_ALIGN, "sc_layernorm_bwd: misaligned");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = (size_t)4 * nsum * width * sizeof(float);
-    const int ch = width <= 512 ? 2 : width <= 768 ? 3 : width <= 1024 ? 4 : 8;
     if (dtype != SC_BF16 && dtype != SC_F32) return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_bwd: bad dtype %d", dtype);
 #define LN_BWD(T, NS, C) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NS, C>), dim3(nblocks), dim3(256), lds_bytes, st, (const T*)dy, x, mean, rstd, gamma, rows, (int)width, dres, dx, (T*)dx_cast, (float*)ws)
 #define LN_BWD_C(T, NS) do { if (ch == 2) LN_BWD(T, NS, 2); else if (ch == 3) LN_BWD(T, NS, 3); else if (ch == 4) LN_BWD(T, NS, 4); else LN_BWD(T, NS, 8); } while (0)

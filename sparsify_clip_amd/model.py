@@ -363,6 +363,9 @@ class ClipModel:
             b[key] = [torch.empty(rows, cols, dtype=dt, device=dev) for _ in range(tower.layers)]
         for key in ["ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd"]:
             b[key] = [torch.empty(rows, dtype=f32, device=dev) for _ in range(tower.layers)]
+        # softmax statistics of every (image, head, query) for the flash-attention form of the backward (long sequences: ViT-L/14's 257 tokens)
+        b["attn_lse"] = ([torch.empty(batch * tower.heads * tower.seq, dtype=f32, device=dev) for _ in range(tower.layers)]
+                         if ops.attention_uses_stats(T, tower.seq) else None)
         # backward scratch shared by both towers (sized for the larger request)
         ws_bytes = ops.block_workspace_bytes(rows, w, mlp, T)
         # the weight-gradient side stream of block k may still read d_h / d_qkv / d_res_t / dx_t while block k+1 runs on the main
@@ -402,6 +405,7 @@ class ClipModel:
             d.x_in, d.x_out, d.x_mid = b["x"][i].data_ptr(), b["x"][i + 1].data_ptr(), b["x_mid"][i].data_ptr()
             for field in ["ln1_out", "qkv", "attn_out", "ln2_out", "h_pre", "h_act", "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd"]:
                 setattr(d, field, b[field][i].data_ptr())
+            d.attn_lse = b["attn_lse"][i].data_ptr() if b["attn_lse"] is not None else None
             for field, pname in [("g_ln1_g", "ln_1.weight"), ("g_ln1_b", "ln_1.bias"), ("g_w_qkv", "attn.in_proj_weight"),
                                  ("g_b_qkv", "attn.in_proj_bias"), ("g_w_o", "attn.out_proj.weight"), ("g_b_o", "attn.out_proj.bias"),
                                  ("g_ln2_g", "ln_2.weight"), ("g_ln2_b", "ln_2.bias"), ("g_w_fc1", "mlp.c_fc.weight"), ("g_b_fc1", "mlp.c_fc.bias"),

@@ -299,18 +299,33 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_cast=False, dgamma=N
     return dx, dx_cast, dgamma, dbeta
 
 
-def attention_fwd(qkv, batch, seq, heads, causal):
+def attention_uses_stats(dtype, seq) -> bool:
+    """Whether the forward writes softmax statistics for this shape (sc_attention_fwd_stats / _bwd_stats: bf16, 80 < seq <= 272)."""
+    return bool(LIB.raw("sc_attention_uses_stats")(sc_dtype(dtype), int(seq)))
+
+
+def attention_fwd(qkv, batch, seq, heads, causal, lse=None):
+    """out; with `lse` (fp32 [batch * heads * seq]) the flash-attention form: the statistics are written where attention_uses_stats says so."""
     rows, w3 = qkv.shape
     w = w3 // 3
     out = torch.empty(rows, w, dtype=qkv.dtype, device=qkv.device)
-    LIB.call("sc_attention_fwd", ptr(qkv), ptr(out), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
+    if lse is not None:
+        LIB.call("sc_attention_fwd_stats", ptr(qkv), ptr(out), ptr(lse), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
+    else:
+        LIB.call("sc_attention_fwd", ptr(qkv), ptr(out), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
     return out
 
 
-def attention_bwd(qkv, d_out, batch, seq, heads, causal, colsum_out=None, colsum_accumulate=False):
-    """d_qkv; with colsum_out ([3*width] fp32) also the column sums of d_qkv over all rows (the in_proj bias gradient)."""
+def attention_bwd(qkv, d_out, batch, seq, heads, causal, colsum_out=None, colsum_accumulate=False, out=None, lse=None):
+    """d_qkv; with colsum_out ([3*width] fp32) also the column sums of d_qkv over all rows (the in_proj bias gradient); with the forward's
+    `out` and `lse` the flash-attention form of the backward (sc_attention_bwd_stats)."""
     w = qkv.shape[1] // 3
     d_qkv = torch.empty_like(qkv)
+    if out is not None and lse is not None:
+        ws = _workspace(max(batch, 4096) * 3 * w * 4, qkv.device) if colsum_out is not None else None
+        LIB.call("sc_attention_bwd_stats", ptr(qkv), ptr(out), ptr(lse), ptr(d_out), ptr(d_qkv), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal),
+                 ptr(colsum_out), int(bool(colsum_accumulate)), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
+        return d_qkv
     if colsum_out is None:
         LIB.call("sc_attention_bwd", ptr(qkv), ptr(d_out), ptr(d_qkv), sc_dtype(qkv.dtype), batch, seq, w, heads, int(causal), stream_ptr())
         return d_qkv

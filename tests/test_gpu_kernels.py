@@ -503,6 +503,26 @@ def test_attention(ops, dtype, seq, heads, causal):
         d_qkv = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal)
         tolb = (1e-4, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
         assert_close(d_qkv, q64.grad, *tolb, "attention bwd")
+        if ops.attention_uses_stats(dtype, seq):
+            # the flash-attention form (sc_attention_fwd_stats / _bwd_stats): same output, lse_i = -log2 sum_j exp(s_ij), and a backward that
+            # takes the statistics and the forward's output instead of recomputing row maxima / sums (delta_i = dO_i . O_i)
+            lse = torch.full((batch * heads * seq,), float("nan"), device=DEV)
+            _poison_lds()
+            out2 = ops.attention_fwd(qkv.to(DEV), batch, seq, heads, causal, lse=lse)
+            assert torch.equal(out2, out), "the statistics forward must not change the output"
+            w = heads * 64
+            q, k, _ = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in qkv.double().split(w, dim=1)]
+            sc = q @ k.transpose(-1, -2) * 0.125
+            if causal:
+                sc = sc + torch.full((seq, seq), float("-inf"), dtype=sc.dtype).triu_(1)
+            assert_close(lse.reshape(batch, heads, seq), -torch.logsumexp(sc, dim=-1) / np.log(2.0), 1e-4, 1e-4, "attention lse")
+            _poison_lds()
+            cs = torch.zeros(3 * w, device=DEV)
+            d2 = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal, colsum_out=cs, out=out2, lse=lse)
+            assert_close(d2, q64.grad, *tolb, "attention bwd (statistics form)")
+            assert_close(cs, d2.double().sum(0), 1e-5, 2e-4, "attention bwd colsum (statistics form)")
+            d3 = ops.attention_bwd(qkv.to(DEV), d_out.to(DEV), batch, seq, heads, causal, out=out2, lse=lse)
+            assert torch.equal(d3, d2), "statistics backward: not bit-stable with / without the column sums"
 
 
 @pytest.mark.parametrize("seq,heads,causal", [(50, 12, False), (77, 8, True), (33, 5, True)])

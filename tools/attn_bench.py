@@ -22,5 +22,12 @@ for name, (b, s, w, h, causal) in shapes.items():
     out = ops.attention_fwd(qkv, b, s, h, causal)
     f = timed(lambda: ops.attention_fwd(qkv, b, s, h, causal))
     g = timed(lambda: ops.attention_bwd(qkv, do, b, s, h, causal))
+    extra = ""
+    if ops.attention_uses_stats(qkv.dtype, s):      # the flash-attention form: statistics from the forward, one sweep in the backward's pass 1
+        lse = torch.empty(b * h * s, device=dev)
+        out = ops.attention_fwd(qkv, b, s, h, causal, lse=lse)
+        f2 = timed(lambda: ops.attention_fwd(qkv, b, s, h, causal, lse=lse))
+        g2 = timed(lambda: ops.attention_bwd(qkv, do, b, s, h, causal, out=out, lse=lse))
+        extra = f"   | with statistics: fwd {f2*1e3:7.1f} us  bwd {g2*1e3:7.1f} us"
     fb = (qkv.numel() + out.numel()) * 2; bb = (2 * qkv.numel() + do.numel()) * 2
-    print(f"attention {name:5s} S={s}: fwd {f*1e3:7.1f} us ({fb/f/1e9:6.2f} TB/s of {fb/1e6:.0f} MB)   bwd {g*1e3:7.1f} us ({bb/g/1e9:6.2f} TB/s of {bb/1e6:.0f} MB)", flush=True)
+    print(f"attention {name:5s} S={s}: fwd {f*1e3:7.1f} us ({fb/f/1e9:6.2f} TB/s of {fb/1e6:.0f} MB)   bwd {g*1e3:7.1f} us ({bb/g/1e9:6.2f} TB/s of {bb/1e6:.0f} MB){extra}", flush=True)

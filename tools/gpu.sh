@@ -2,7 +2,7 @@
 # The one GPU-box driver script (run through gpurun from the repo root):   bash tools/gpu.sh <task> [<task> ...]
 # Tasks run in the order given and stop at the first failing one.  Everything logs under gpurun_out/ (merged back by gpurun);
 # what should be judged is copied from there into profiles/ by hand.  rocprofv3 always gets the python program directly after `--`.
-#   tests        python -m pytest tests -m gpu            -> gpurun_out/pytest_gpu.log            (PYTEST_ARGS to narrow)
+#   tests        python -m pytest tests -m gpu            -> gpurun_out/pytest_gpu.log            (PYTEST_ARGS / PYTEST_PATHS to narrow)
 #   bench        python bench.py (default: global batch 8192; BENCH_ARGS="--local-batch 1024" = the 1024-pair shard) -> gpurun_out/bench.json / bench.err    (BENCH_ARGS, STEPS)
 #   prof         rocprofv3 --kernel-trace --stats of bench.py (3 steps)          -> gpurun_out/prof/bench_kernel_stats.csv
 #   replay       rocprofv3 --kernel-trace --stats of tools/gemm_replay.py (ONE stream: bench.py's roofline launch set)
@@ -36,7 +36,7 @@ for task in "$@"; do
   cd $R
   case $task in
     tests)
-      timeout -k 10 ${TEST_TIMEOUT:-1100} python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1; rc=$?
+      timeout -k 10 ${TEST_TIMEOUT:-1100} python -m pytest ${PYTEST_PATHS:-tests} -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1; rc=$?
       echo "pytest rc=$rc"; tail -5 gpurun_out/pytest_gpu.log; grep -E "^FAILED|^ERROR" gpurun_out/pytest_gpu.log | head -20
       [ $rc = 0 ] || exit $rc ;;
     bench)

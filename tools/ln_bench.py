@@ -26,7 +26,10 @@ def timed(fn, iters=20):
 def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    for name, rows, w in (("image", 51200, 768), ("text", 78848, 512)):
+    shapes = (("image", 51200, 768), ("text", 78848, 512))
+    if os.environ.get("LN_L14"):      # ViT-L/14 at local batch 512 (BASELINE config 5)
+        shapes = (("L/14 image", 131584, 1024), ("L/14 text", 39424, 768))
+    for name, rows, w in shapes:
         x = torch.randn(rows, w, device=dev)
         g = torch.randn(w, device=dev)
         b = torch.randn(w, device=dev)
@@ -39,7 +42,7 @@ def main():
         t_f = timed(lambda: ops.layernorm_fwd(x, g, b, torch.bfloat16, out=y))
         t_b = timed(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dres=dres, want_cast=True, dgamma=dg, dbeta=db, accumulate=True, dx_colsum=dc))
         bf, bb = n * 6, n * 16
-        print(f"layernorm {name:5s} [{rows}x{w}]: fwd {t_f:7.1f} us ({bf / t_f / 1e6:5.2f} TB/s of {bf / 1e6:.0f} MB)   "
+        print(f"layernorm {name:10s} [{rows}x{w}]: fwd {t_f:7.1f} us ({bf / t_f / 1e6:5.2f} TB/s of {bf / 1e6:.0f} MB)   "
               f"bwd+reduce {t_b:7.1f} us ({bb / t_b / 1e6:5.2f} TB/s of {bb / 1e6:.0f} MB)")
 
 
