@@ -288,6 +288,12 @@ class DeviceAugLoader:
                     q.get_nowait()
                 except queue.Empty:
                     th.join(0.05)
+            # an abandoned iteration (break, exception, closed generator) leaves slots the producer had claimed and copies that may still
+            # be in flight: wait for the copy stream and hand every slot back, so that the next __iter__ starts from a clean stage
+            # instead of waiting for a slot nobody will free
+            self._copy_stream.synchronize()
+            for s_ in self._stage:
+                s_["free"].set()
 
 
 def coco_paths(split: str):

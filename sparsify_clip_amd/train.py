@@ -268,6 +268,7 @@ class Trainer:
         opt = self.optimizer
         st = {"adam_m": opt.m.detach().cpu(), "adam_v": opt.v.detach().cpu(),
               "counters": torch.tensor([opt.steps, self.current_batch, self.epoch, self.scheduler.last_epoch], dtype=torch.int64),
+              "run": torch.tensor([self.t_total, self.config["epochs"]], dtype=torch.int64),      # the schedule's span: a resume continues THIS run
               "weights": torch.tensor([self.beta, self.alpha], dtype=torch.float64)}
         if self.learnable_t:
             val, grad, em, ev = opt.extra_state[id(self.temperature)]
@@ -282,6 +283,11 @@ class Trainer:
         opt.m.copy_(st["adam_m"]), opt.v.copy_(st["adam_v"])
         opt.steps, self.current_batch, self.epoch, last = (int(v) for v in st["counters"])
         self.beta, self.alpha = (float(v) for v in st["weights"])
+        if "run" in st and int(st["run"][0]) != self.t_total:
+            # the LR schedule and the alpha / beta ramps are functions of the ORIGINAL run's total step count (reference :734-736, :41-64):
+            # rebuild them from it, whatever `epochs` the resuming config carries
+            self.t_total = int(st["run"][0])
+            self.scheduler = get_cosine_schedule_with_warmup(self.optimizer, int(0.20 * self.t_total), self.t_total, config=self.config)
         self.scheduler.last_epoch = last
         lrs = [base * lmbda(last) for lmbda, base in zip(self.scheduler.lr_lambdas, self.scheduler.base_lrs)]
         for g, lr in zip(opt.param_groups, lrs):
@@ -402,21 +408,34 @@ def train_model(config, train_loader, test_loader, device, logger=None):
     """Reference :682-986."""
     trainer = Trainer(config, device, len(train_loader), logger)
     model = trainer.model
-    start_epoch = 0
+    start_epoch, end_epoch = 0, config["epochs"]
     if config["resume_checkpoint"]:   # :719-724 (weights only, `module.`-prefixed keys accepted)
         model.load_state_dict(torch.load(config["resume_checkpoint"], map_location="cpu", weights_only=True))
         start_epoch = config.get("resume_epoch", 0)
+        end_epoch = start_epoch + config["epochs"]      # the reference runs a further full `epochs` (:749)
         sidecar = sidecar_path(config["resume_checkpoint"])
-        if os.path.exists(sidecar):   # optimiser moments, step counters, schedule position, temperature: continue where the run stopped
-            trainer.load_full_state(torch.load(sidecar, map_location="cpu", weights_only=True))
+        if config.get("full_state_checkpoint"):   # opt-in: optimiser moments, step counters, schedule position, temperature - continue the ORIGINAL run
+            if not os.path.exists(sidecar):
+                raise ScError(f"full_state_checkpoint: {sidecar} is missing next to the checkpoint")
+            st = torch.load(sidecar, map_location="cpu", weights_only=True)
+            trainer.load_full_state(st)
             trainer.optimizer.model.refresh_shadows(full=True)
             start_epoch = trainer.epoch + 1
+            end_epoch = int(st["run"][1]) if "run" in st else start_epoch + config["epochs"]      # the epochs the original run had left
     if len(train_loader) == 0:
         raise ScError("training loader yields no batches (num_train_samples < batch_size with drop_last, SURVEY 0.10)")
+    micro = int(config.get("micro_batch") or 0)
+    if micro > 0:   # checked before the first evaluation, not at the first training step
+        if model.rn is not None:
+            raise ScError("micro_batch: the ModifiedResNet tower normalises over the batch (BatchNorm); micro-batches would change the result")
+        per_rank = config["batch_size"] // max(1, D.world_size())
+        if per_rank % micro:
+            raise ScError(f"micro_batch {micro} does not divide the {per_rank} pairs a rank processes per step")
+        if config.get("text_trim"):
+            raise ScError("micro_batch and text_trim cannot be combined (step_cached runs every position)")
     evaluate_model(model, test_loader, device, logger=logger)   # :740
-    for epoch in range(start_epoch, start_epoch + config["epochs"]):
+    for epoch in range(start_epoch, end_epoch):
         trainer.epoch = epoch
-        micro = int(config.get("micro_batch") or 0)
         for images, captions in train_loader:
             if 0 < micro < images.shape[0]:
                 trainer.step_cached(images, captions, micro)

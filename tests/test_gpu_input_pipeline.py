@@ -80,6 +80,22 @@ def test_loader_train_and_eval_match_the_cpu_pipeline(gpu):
             assert not torch.equal(list(a)[0][0], ba[0][0])
 
 
+@pytest.mark.timeout(120)
+def test_loader_survives_an_abandoned_iteration(gpu):
+    """A consumer that stops mid-epoch (break) leaves staging slots claimed by the producer thread; the loader hands them back and the
+    next iteration runs to the end (it used to wait for a slot nobody would free)."""
+    from sparsify_clip_amd.input_pipeline import DeviceAugLoader, SyntheticCocoDataset
+    ds = SyntheticCocoDataset(64, seed=3, pool=7)
+    loader = DeviceAugLoader(ds, 8, gpu, train=False, seed=5, workers=2)
+    ref = [x[0].clone() for x in DeviceAugLoader(ds, 8, gpu, train=False, seed=5, workers=2)]
+    assert len(ref) == 8
+    for k, (images, _) in enumerate(loader):
+        if k == 1:
+            break
+    again = [x[0].clone() for x in loader]
+    assert len(again) == 8 and all(torch.equal(a, b) for a, b in zip(again, ref))
+
+
 def test_coco_directory_through_the_runner_loader(gpu, tmp_path, monkeypatch):
     """A COCO-format fixture (PNG files + captions JSON in the reference's directory layout, :995-1001) read by CocoCaptionsDataset and
     served by train.dataset_loader with synthetic: False - the reference's dataset_loader(config) contract."""

@@ -197,20 +197,19 @@ def test_full_state_sidecar_resume_is_bit_exact(gpu, tmp_path, monkeypatch):
     sd2 = torch.load("models/sc_epoch_2.pt", map_location="cpu", weights_only=True)
     st2 = torch.load("models/sc_epoch_2.state.pt", map_location="cpu", weights_only=True)
     assert set(st2) >= {"adam_m", "adam_v", "counters", "weights", "temperature"} and st2["counters"].tolist()[1:3] == [6, 1]
-    # the 4-epoch run's LR schedule spans 12 steps: resume with the same total so the schedule continues (epochs = 2 more of 4)
+    assert st2["run"].tolist() == [12, 4]      # the schedule's span travels with the sidecar
+    # the 4-epoch run's LR schedule spans 12 steps; the resuming config says `epochs: 3` - the sidecar wins: the schedule is rebuilt over 12
+    # steps and the run does the 2 epochs the original had left
     T.os.rename("models/sc_epoch_2.pt", "models/keep.pt"), T.os.rename("models/sc_epoch_2.state.pt", "models/keep.state.pt")
-    cfg_resume = {"resume_checkpoint": "models/keep.pt", "epochs": 2, "run_name": "sc2"}
-    real_trainer = T.Trainer
-
-    class ResumeTrainer(real_trainer):      # same t_total as the uninterrupted run (the reference derives it from config["epochs"])
-        def __init__(self, config, device, steps_per_epoch, logger=None, model=None):
-            super().__init__(dict(config, epochs=4), device, steps_per_epoch, logger, model)
-
-    monkeypatch.setattr(T, "Trainer", ResumeTrainer)
+    cfg_resume = {"resume_checkpoint": "models/keep.pt", "epochs": 3, "run_name": "sc2"}
     w_resumed = run(cfg_resume, b_losses)
     assert b_losses == full_losses[6:], (b_losses, full_losses)
     assert torch.equal(w_resumed, w_full)
     assert sd2.keys() == torch.load("models/sc2_epoch_4.pt", map_location="cpu", weights_only=True).keys()
+    # without the opt-in key the side-car is ignored: weights only, a further full `epochs`, as the reference resumes (:719-724)
+    c_losses = []
+    run({"resume_checkpoint": "models/keep.pt", "epochs": 1, "run_name": "sc3", "full_state_checkpoint": False, "save_checkpoint_every_n_epochs": 9}, c_losses)
+    assert len(c_losses) == 3 and c_losses != full_losses[6:9]
 
 
 @pytest.mark.gpu
