@@ -700,6 +700,18 @@ __device__ __forceinline__ uint4 pack8_bf16(const f32x4& v0, const f32x4& v1) {
     return u;
 }
 
+// 16-byte unit of piece p (4 fp32 columns) of slab row `row`.  bf16 outputs: a lane stores 8 consecutive columns (pieces 2 ep, 2 ep + 1 ->
+// one 16-byte store, 128 contiguous bytes per row and instruction) and p ^ row keeps both the accumulator writes (8 rows, one piece) and
+// the row-major reads apart.  fp32 output (NTP_RESID): with the same ownership every load / store instruction touched HALF of each 32-byte
+// run (16 of every 32 bytes: twice the memory requests for the same bytes, and the epilogue was bound by the CU's request rate, not by the
+// chip - tools/epi_half_chip.py); there a lane owns pieces ep and 8 + ep, so one instruction covers 128 contiguous bytes of a row, and the
+// unit is p ^ (row & 7) ^ 8 * bit 1 of row (conflict-free for the 8-row writes and for the 4-row x 4-piece groups of a ds_read_b128).
+template <int EPI>
+__device__ __forceinline__ unsigned ntp_slab_unit(unsigned p, unsigned row) {
+    if constexpr (EPI == NTP_RESID) return p ^ (row & 7u) ^ (((row >> 1) & 1u) << 3);
+    else return (p ^ row) & 15u;
+}
+
 template <int EPI, int I>
 __device__ __forceinline__ void ntp_aux_load(NtpAux<EPI>& x, const NtpEpi& c) {
 #pragma unroll
@@ -708,7 +720,7 @@ __device__ __forceinline__ void ntp_aux_load(NtpAux<EPI>& x, const NtpEpi& c) {
         if constexpr (EPI == NTP_DGELU) x.hpre[g] = *(const uint4*)(row + c.voff_aux);
         if constexpr (EPI == NTP_RESID) {
             x.r0[g] = *(const f32x4*)(row + c.voff_aux);
-            x.r1[g] = *(const f32x4*)(row + c.voff_aux + 16);
+            x.r1[g] = *(const f32x4*)(row + c.voff_aux + 128);
         }
     }
 }
@@ -726,8 +738,9 @@ __device__ __forceinline__ void ntp_row_tile(const NtpEpi& c, int lane, const Nt
     for (int g = 0; g < 2; ++g) {
         const int row = 8 * g + erow;
         const char* rd = c.slab + row * 256;
-        f32x4 v0 = *(const f32x4*)(rd + (((2 * ep) ^ row) << 4)) + c.bias0;
-        f32x4 v1 = *(const f32x4*)(rd + (((2 * ep + 1) ^ row) << 4)) + c.bias1;
+        const unsigned p0 = EPI == NTP_RESID ? ep : 2 * ep, p1 = EPI == NTP_RESID ? 8 + ep : 2 * ep + 1;
+        f32x4 v0 = *(const f32x4*)(rd + (ntp_slab_unit<EPI>(p0, row) << 4)) + c.bias0;
+        f32x4 v1 = *(const f32x4*)(rd + (ntp_slab_unit<EPI>(p1, row) << 4)) + c.bias1;
         const size_t rsel = (size_t)(16 * I + 8 * g);
         if constexpr (EPI == NTP_GELU_PRE) {
             *(uint4*)(c.pre + rsel * c.row_bytes_pre + c.voff_pre) = pack8_bf16(v0, v1);
@@ -741,7 +754,7 @@ __device__ __forceinline__ void ntp_row_tile(const NtpEpi& c, int lane, const Nt
             v0 += x.r0[g]; v1 += x.r1[g];
             char* cp = c.c + rsel * c.row_bytes_c + c.voff_c;
             *(f32x4*)cp = v0;
-            *(f32x4*)(cp + 16) = v1;
+            *(f32x4*)(cp + 128) = v1;
         } else {
             const uint4 u = pack8_bf16(v0, v1);
             *(uint4*)(c.c + rsel * c.row_bytes_c + c.voff_c) = u;
@@ -966,7 +979,7 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
 
     // ---- epilogue of the tile
     {
-        const int erow = lane >> 3, ecol = (lane & 7) * 8;
+        const int erow = lane >> 3, ecol = (lane & 7) * (OUT_F32 ? 4 : 8);   // fp32: columns 4 ep .. and 32 + 4 ep .. (ntp_slab_unit)
         const int mw = cur.m0 + wm * (HALF ? 64 : 128), nw = cur.n0 + wn * 64;
         NtpEpi c;
         constexpr int ES = OUT_F32 ? 4 : 2;
@@ -991,9 +1004,9 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
         }
         c.slab = smem + 2 * B_STAGE + wave * P_SLAB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c.slab_wr[j] = lds0 + 2 * B_STAGE + wave * P_SLAB + frow * 256 + (((4 * j + fq) ^ frow) << 4);
+        for (int j = 0; j < 4; ++j) c.slab_wr[j] = lds0 + 2 * B_STAGE + wave * P_SLAB + frow * 256 + (ntp_slab_unit<EPI>(4 * j + fq, frow) << 4);
         c.bias0 = f32x4{0.f, 0.f, 0.f, 0.f}; c.bias1 = c.bias0;
-        if (e_bias) { c.bias0 = *(const f32x4*)(e_bias + nw + ecol); c.bias1 = *(const f32x4*)(e_bias + nw + ecol + 4); }
+        if (e_bias) { c.bias0 = *(const f32x4*)(e_bias + nw + ecol); c.bias1 = *(const f32x4*)(e_bias + nw + ecol + (OUT_F32 ? 32 : 4)); }
         const bool do_cs = EPI == NTP_DGELU && e.cs_partial != nullptr;
         f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
         constexpr int AD = ntp_aux_depth<EPI>() - (STAMP && ntp_aux_depth<EPI>() > 1 ? 1 : 0);   // the diagnostic instances keep their time stamps in registers
