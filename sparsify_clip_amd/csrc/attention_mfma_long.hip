@@ -637,6 +637,206 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void attn_bwd_long2_kernel(const b
     }
 }
 
+// column sums of one tile (values as stored: bf16-rounded; rows beyond the sequence excluded) added to the wave's 64 floats in LDS: the
+// running sums of the kernels above cost 16 registers per output, which the kernel below does not have
+__device__ __forceinline__ void cs_tile_to_lds(float* dst, const f32x4 (&v)[4], bool live, int c16, int g) {
+    f32x4 t[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[dt][r] = live ? bf16_to_f32(f32_to_bf16(v[dt][r])) : 0.f;
+    cs_rows(t);
+    if (c16 == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(f32x4*)(dst + 16 * dt + 4 * g) += t[dt];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, long sequences, two LDS phases
+// The statistics form of the kernel above with HALF its LDS: pass 1 (lane = query row) only needs the K and V images, pass 2 (lane = key
+// row) only the Q and dO images, and a wave's own row fragments (Q / dO in pass 1, K / V in pass 2) come straight from global memory, one
+// tile ahead.  76 KiB instead of 139 KiB and <= 128 registers: TWO workgroups (16 waves, 4 per SIMD) per CU, so that one head's staging,
+// barriers and the uneven deal of 17 tiles to 8 waves are covered by the other head's waves.  lse and delta = dO . O of every row are taken
+// once per head by all threads (8 lanes per row, coalesced) into LDS instead of per query tile out of fragment loads.
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale,
+                                                                float* cs_part /* [batch][3 W] or null */, const bf16_t* fwd_out, const float* lse) {
+    constexpr int NW = 8;
+    constexpr int KS = (NT + 1) / 2;
+    constexpr bool ODD = (NT & 1) != 0;
+    constexpr int IMG = NT * 16 * LDR;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_b3[];
+    bf16_t* Ia = lds_b3;                    // pass 1: K, pass 2: Q
+    bf16_t* Ib = Ia + IMG;                  // pass 1: V, pass 2: dO
+    float* st_e = (float*)(Ib + IMG);       // lse_i (-inf beyond the sequence)
+    float* st_dl = st_e + NT * 16;          // -scale delta_i
+    float* red = st_dl + NT * 16;           // [NW][192] column sums of dq | dk | dv
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int64_t ld = 3 * (int64_t)W;
+    const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    const bf16_t* dob = d_out + (int64_t)b * S * W + h * HD;
+    const bf16_t* fob = fwd_out + (int64_t)b * S * W + h * HD;
+    bf16_t* dqb = d_qkv + (int64_t)b * S * ld + h * HD;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int n_t = (S + 15) >> 4;
+    const float c = scale * 1.4426950408889634f;   // exp(x scale) = 2^(x c)
+
+    // the wave's first query tile: fragments requested in front of the staging
+    bf16x8 q0 = row_frag_global(qb, ld, wave, 0, lane, S), q1 = row_frag_global(qb, ld, wave, 1, lane, S);
+    bf16x8 g0 = row_frag_global(dob, W, wave, 0, lane, S), g1 = row_frag_global(dob, W, wave, 1, lane, S);
+    stage_head_block(Ia, qb + W, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Ib, qb + 2 * W, ld, S, NT * 16, tid, 64 * NW);
+    for (int x = tid; x < NW * 192; x += 64 * NW) red[x] = 0.f;
+    for (int r = tid >> 3; r < NT * 16; r += 8 * NW) {   // statistics: 8 lanes per row, 16 bytes of dO and O each
+        float dot = 0.f;
+        if (r < S) {
+            const uint4 a = *(const uint4*)(dob + (int64_t)r * W + (tid & 7) * 8), o = *(const uint4*)(fob + (int64_t)r * W + (tid & 7) * 8);
+            const unsigned av[4] = {a.x, a.y, a.z, a.w}, ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dot += __uint_as_float(av[e] << 16) * __uint_as_float(ov[e] << 16) + __uint_as_float(av[e] & 0xffff0000u) * __uint_as_float(ov[e] & 0xffff0000u);
+        }
+        dot += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(dot), 0xB1, 0xF, 0xF, true));    // lanes xor 1
+        dot += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(dot), 0x4E, 0xF, 0xF, true));    // lanes xor 2
+        dot += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(dot), 0x141, 0xF, 0xF, true));   // the other quad of the 8 lanes
+        if ((tid & 7) == 0) {
+            st_e[r] = r < S ? lse[(int64_t)blockIdx.x * S + r] : -INFINITY;
+            st_dl[r] = r < S ? -dot * scale : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- pass 1: lane = query row i; Ia = K, Ib = V
+    for (int it = wave; it < n_t; it += NW) {
+        bf16x8 nq0 = q0, nq1 = q1, ng0 = g0, ng1 = g1;
+        if (it + NW < n_t) {   // the next tile's fragments, under this tile's arithmetic
+            nq0 = row_frag_global(qb, ld, it + NW, 0, lane, S); nq1 = row_frag_global(qb, ld, it + NW, 1, lane, S);
+            ng0 = row_frag_global(dob, W, it + NW, 0, lane, S); ng1 = row_frag_global(dob, W, it + NW, 1, lane, S);
+        }
+        const int i = it * 16 + c16;
+        const bool live = i < S;
+        const int jt_end = CAUSAL ? min(n_t, it + 1) : n_t;
+        const float ei = st_e[i], nds = st_dl[i];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < KS; ++s) {
+            if (2 * s >= jt_end) break;
+            f32x4 ds[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jt = 2 * s + u;
+                ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jt >= jt_end) continue;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                a = MFMA16(row_frag_lds(Ia, jt, 0, lane), q0, a);
+                a = MFMA16(row_frag_lds(Ia, jt, 1, lane), q1, a);
+                d = MFMA16(row_frag_lds(Ib, jt, 0, lane), g0, d);
+                d = MFMA16(row_frag_lds(Ib, jt, 1, lane), g1, d);
+                const bool edge = jt * 16 + 16 > S || (CAUSAL && jt == it);   // the only tiles with masked pairs (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], c, ei));
+                    if (edge) {
+                        const int j = jt * 16 + 4 * g + r;
+                        p = (j < S && (!CAUSAL || j <= i)) ? p : 0.f;
+                    }
+                    ds[u][r] = p * __builtin_fmaf(d[r], scale, nds);
+                }
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+            const bool hi_valid = !(ODD && s == KS - 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kt = hi_valid ? tr_frag<true>(Ia, s, 16 * dt, lane) : tr_frag<false>(Ia, s, 16 * dt, lane);
+                dq[dt] = MFMA16(kt, dsf, dq[dt]);
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
+        }
+        if (cs_part) cs_tile_to_lds(red + wave * 192, dq, live, c16, g);
+        q0 = nq0; q1 = nq1; g0 = ng0; g1 = ng1;
+    }
+    // the wave's first key tile: K / V rows from global, requested in front of the second staging
+    bf16x8 k0 = row_frag_global(qb + W, ld, wave, 0, lane, S), k1 = row_frag_global(qb + W, ld, wave, 1, lane, S);
+    bf16x8 v0 = row_frag_global(qb + 2 * W, ld, wave, 0, lane, S), v1 = row_frag_global(qb + 2 * W, ld, wave, 1, lane, S);
+    __syncthreads();   // every wave is done with the K and V images
+    stage_head_block(Ia, qb, ld, S, NT * 16, tid, 64 * NW);
+    stage_head_block(Ib, dob, W, S, NT * 16, tid, 64 * NW);
+    __syncthreads();
+
+    // ---------------- pass 2: lane = key row j; Ia = Q, Ib = dO
+    for (int jt = wave; jt < n_t; jt += NW) {
+        if (jt != wave) {   // (no room to hold the next tile's fragments beside this tile's: the CU's other waves cover the round trip)
+            k0 = row_frag_global(qb + W, ld, jt, 0, lane, S); k1 = row_frag_global(qb + W, ld, jt, 1, lane, S);
+            v0 = row_frag_global(qb + 2 * W, ld, jt, 0, lane, S); v1 = row_frag_global(qb + 2 * W, ld, jt, 1, lane, S);
+        }
+        const int j = jt * 16 + c16;
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < KS; ++s) {
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pt[u] = dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int it = 2 * s + u;
+                if (ODD && it >= NT) continue;
+                if (it >= n_t) continue;
+                if (CAUSAL && it < jt) continue;    // query tile entirely in the past of this key tile: P^T = dS^T = 0
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                a = MFMA16(row_frag_lds(Ia, it, 0, lane), k0, a);
+                a = MFMA16(row_frag_lds(Ia, it, 1, lane), k1, a);
+                d = MFMA16(row_frag_lds(Ib, it, 0, lane), v0, d);
+                d = MFMA16(row_frag_lds(Ib, it, 1, lane), v1, d);
+                const f32x4 mm = *(const f32x4*)(st_e + it * 16 + 4 * g), dl = *(const f32x4*)(st_dl + it * 16 + 4 * g);
+                // rows beyond the sequence carry lse = -inf (p = 0); keys beyond it only produce lanes that are never stored
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], c, mm[r]));
+                    if (CAUSAL && it == jt) p = (j <= it * 16 + 4 * g + r) ? p : 0.f;
+                    pt[u][r] = p;
+                    dst[u][r] = p * __builtin_fmaf(d[r], scale, dl[r]);
+                }
+            }
+            if (CAUSAL && 2 * s + 1 < jt) continue;
+            if (2 * s >= n_t) continue;
+            const bf16x8 pf = pack_frag(pt[0], pt[1]), dsf = pack_frag(dst[0], dst[1]);
+            const bool hi_valid = !(ODD && s == KS - 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 ot = hi_valid ? tr_frag<true>(Ib, s, 16 * dt, lane) : tr_frag<false>(Ib, s, 16 * dt, lane);
+                const bf16x8 qt = hi_valid ? tr_frag<true>(Ia, s, 16 * dt, lane) : tr_frag<false>(Ia, s, 16 * dt, lane);
+                dv[dt] = MFMA16(ot, pf, dv[dt]);
+                dk[dt] = MFMA16(qt, dsf, dk[dt]);
+            }
+        }
+        if (j < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + W + 16 * dt + 4 * g, dk[dt]);
+                io<bf16_t>::st4(dqb + (int64_t)j * ld + 2 * W + 16 * dt + 4 * g, dv[dt]);
+            }
+        }
+        if (cs_part) { cs_tile_to_lds(red + wave * 192 + 64, dk, j < S, c16, g); cs_tile_to_lds(red + wave * 192 + 128, dv, j < S, c16, g); }
+    }
+    if (cs_part) {   // the waves' sums over their tiles -> the head's 192 columns for image b, waves added in a fixed order
+        __syncthreads();
+        if (tid < 192) {
+            float v = red[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) v += red[w2 * 192 + tid];
+            cs_part[(int64_t)b * 3 * W + (tid >> 6) * W + h * HD + (tid & 63)] = v;
+        }
+    }
+}
+
 template <typename K>
 int reserve_lds(K kernel, size_t bytes) {
     if (bytes > 65536) {
@@ -714,6 +914,24 @@ int launch_bwd_long2(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
     return SC_OK;
 }
 
+template <int NT>
+int launch_bwd_long3(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, float* cs_part,
+                     hipStream_t st, const void* fwd_out, const float* lse) {
+    const size_t lds = ((size_t)2 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)2 * NT * 16 * sizeof(float) + (size_t)8 * 192 * sizeof(float);
+    const dim3 grid((unsigned)(batch * heads));
+    if (causal) {
+        SC_TRY(reserve_lds(attn_bwd_long3_kernel<NT, true>, lds));
+        hipLaunchKernelGGL((attn_bwd_long3_kernel<NT, true>), grid, dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width,
+                           (int)heads, 0.125f, cs_part, (const bf16_t*)fwd_out, lse);
+    } else {
+        SC_TRY(reserve_lds(attn_bwd_long3_kernel<NT, false>, lds));
+        hipLaunchKernelGGL((attn_bwd_long3_kernel<NT, false>), grid, dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)d_out, (bf16_t*)d_qkv, (int)seq, (int)width,
+                           (int)heads, 0.125f, cs_part, (const bf16_t*)fwd_out, lse);
+    }
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
 }  // namespace
 
 // bf16, one workgroup per head, one wave per 16-row tile of the head where that fits (seq <= 64: 4 waves, <= 80: 5 waves) and
@@ -754,5 +972,7 @@ int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64
     static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variant (A/B)
     if (old_long) return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     const bool stats = fwd_out && lse && sc_attention_long_uses_stats(seq);
+    static const bool one_phase = [] { const char* e = getenv("SC_ATTENTION_LONG3"); return e && e[0] == '0'; }();   // =0: all four images in LDS, one workgroup per CU (A/B)
+    if (stats && !one_phase) return launch_bwd_long3<NT_LONG>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st, fwd_out, lse);
     return launch_bwd_long2<NT_LONG, 8>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st, stats ? fwd_out : nullptr, stats ? lse : nullptr);
 }
