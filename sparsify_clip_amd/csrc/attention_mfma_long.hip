@@ -661,7 +661,7 @@ __device__ __forceinline__ void cs_tile_to_lds(float* dst, const f32x4 (&v)[4], 
 template <int NT, bool CAUSAL>
 __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qkv, const bf16_t* d_out, bf16_t* d_qkv, int S, int W, int H, float scale,
                                                                 float* cs_part /* [batch][3 W] or null */, const bf16_t* fwd_out, const float* lse) {
-    constexpr int NW = 8;
+    constexpr int NW = 8, CW = 4;           // waves; waves that share a lone last tile
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     constexpr int IMG = NT * 16 * LDR;
@@ -671,6 +671,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
     float* st_e = (float*)(Ib + IMG);       // lse_i (-inf beyond the sequence)
     float* st_dl = st_e + NT * 16;          // -scale delta_i
     float* red = st_dl + NT * 16;           // [NW][192] column sums of dq | dk | dv
+    float* part = red + NW * 192;           // [CW][128] partial rows of the lone tile (dq; then dk | dv)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -682,6 +683,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
     const int g = lane >> 4, c16 = lane & 15;
     const int n_t = (S + 15) >> 4;
     const float c = scale * 1.4426950408889634f;   // exp(x scale) = 2^(x c)
+    // A last tile of ONE row that would be some wave's extra tile (S = 257: 16 whole tiles + the class token's row; dealt out whole it
+    // makes wave 0 work three tiles where the others work two): waves 0 .. CW-1 take every CW-th pair of its inner tiles after their own
+    // tiles, the partial rows meet in LDS behind the pass's barrier.
+    const bool lone = n_t > NW && n_t % NW == 1 && S % 16 == 1;
+    const int n_own = lone ? n_t - 1 : n_t;
 
     // the wave's first query tile: fragments requested in front of the staging
     bf16x8 q0 = row_frag_global(qb, ld, wave, 0, lane, S), q1 = row_frag_global(qb, ld, wave, 1, lane, S);
@@ -709,21 +715,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
     __syncthreads();
 
     // ---------------- pass 1: lane = query row i; Ia = K, Ib = V
-    for (int it = wave; it < n_t; it += NW) {
-        bf16x8 nq0 = q0, nq1 = q1, ng0 = g0, ng1 = g1;
-        if (it + NW < n_t) {   // the next tile's fragments, under this tile's arithmetic
-            nq0 = row_frag_global(qb, ld, it + NW, 0, lane, S); nq1 = row_frag_global(qb, ld, it + NW, 1, lane, S);
-            ng0 = row_frag_global(dob, W, it + NW, 0, lane, S); ng1 = row_frag_global(dob, W, it + NW, 1, lane, S);
-        }
+    // dq of query tile `it` over the key-tile pairs s0, s0 + sstep, ...
+    auto pass1 = [&](int it, const bf16x8& q0, const bf16x8& q1, const bf16x8& g0, const bf16x8& g1, int s0, int sstep, f32x4 (&dq)[4]) {
         const int i = it * 16 + c16;
-        const bool live = i < S;
         const int jt_end = CAUSAL ? min(n_t, it + 1) : n_t;
         const float ei = st_e[i], nds = st_dl[i];
-        f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int s = 0; s < KS; ++s) {
+        for (int s = s0; s < KS; s += sstep) {
             if (2 * s >= jt_end) break;
             f32x4 ds[2];
 #pragma unroll
@@ -755,12 +755,31 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
                 dq[dt] = MFMA16(kt, dsf, dq[dt]);
             }
         }
-        if (live) {
+    };
+    for (int it = wave; it < n_own; it += NW) {
+        bf16x8 nq0 = q0, nq1 = q1, ng0 = g0, ng1 = g1;
+        const int itn = it + NW < n_own ? it + NW : (lone && wave < CW ? n_t - 1 : -1);   // the next own tile, then the lone tile
+        if (itn >= 0) {   // its fragments, under this tile's arithmetic
+            nq0 = row_frag_global(qb, ld, itn, 0, lane, S); nq1 = row_frag_global(qb, ld, itn, 1, lane, S);
+            ng0 = row_frag_global(dob, W, itn, 0, lane, S); ng1 = row_frag_global(dob, W, itn, 1, lane, S);
+        }
+        f32x4 dq[4];
+        pass1(it, q0, q1, g0, g1, 0, 1, dq);
+        const int i = it * 16 + c16;
+        if (i < S) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(dqb + (int64_t)i * ld + 16 * dt + 4 * g, dq[dt]);
         }
-        if (cs_part) cs_tile_to_lds(red + wave * 192, dq, live, c16, g);
+        if (cs_part) cs_tile_to_lds(red + wave * 192, dq, i < S, c16, g);
         q0 = nq0; q1 = nq1; g0 = ng0; g1 = ng1;
+    }
+    if (lone && wave < CW) {   // this wave's share of the lone query row (lane c16 == 0 of every lane group holds its 16 of the 64 columns)
+        f32x4 dq[4];
+        pass1(n_t - 1, q0, q1, g0, g1, wave, CW, dq);
+        if (c16 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(part + wave * 128 + 16 * dt + 4 * g) = dq[dt];
+        }
     }
     // the wave's first key tile: K / V rows from global, requested in front of the second staging
     bf16x8 k0 = row_frag_global(qb + W, ld, wave, 0, lane, S), k1 = row_frag_global(qb + W, ld, wave, 1, lane, S);
@@ -768,20 +787,23 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
     __syncthreads();   // every wave is done with the K and V images
     stage_head_block(Ia, qb, ld, S, NT * 16, tid, 64 * NW);
     stage_head_block(Ib, dob, W, S, NT * 16, tid, 64 * NW);
+    if (lone && tid < 64) {   // the lone query row: partial rows in wave order; wave 0 owns red[0 .. 191]
+        float v = part[tid];
+#pragma unroll
+        for (int w2 = 1; w2 < CW; ++w2) v += part[w2 * 128 + tid];
+        const bf16_t o = f32_to_bf16(v);
+        dqb[(int64_t)(S - 1) * ld + tid] = o;
+        if (cs_part) red[tid] += bf16_to_f32(o);
+    }
     __syncthreads();
 
     // ---------------- pass 2: lane = key row j; Ia = Q, Ib = dO
-    for (int jt = wave; jt < n_t; jt += NW) {
-        if (jt != wave) {   // (no room to hold the next tile's fragments beside this tile's: the CU's other waves cover the round trip)
-            k0 = row_frag_global(qb + W, ld, jt, 0, lane, S); k1 = row_frag_global(qb + W, ld, jt, 1, lane, S);
-            v0 = row_frag_global(qb + 2 * W, ld, jt, 0, lane, S); v1 = row_frag_global(qb + 2 * W, ld, jt, 1, lane, S);
-        }
+    auto pass2 = [&](int jt, const bf16x8& k0, const bf16x8& k1, const bf16x8& v0, const bf16x8& v1, int s0, int sstep, f32x4 (&dk)[4], f32x4 (&dv)[4]) {
         const int j = jt * 16 + c16;
-        f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int s = 0; s < KS; ++s) {
+        for (int s = s0; s < KS; s += sstep) {
             f32x4 pt[2], dst[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -817,6 +839,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
                 dk[dt] = MFMA16(qt, dsf, dk[dt]);
             }
         }
+    };
+    for (int jt = wave; jt < n_own; jt += NW) {
+        if (jt != wave) {   // (no room to hold the next tile's fragments beside this tile's: the CU's other waves cover the round trip)
+            k0 = row_frag_global(qb + W, ld, jt, 0, lane, S); k1 = row_frag_global(qb + W, ld, jt, 1, lane, S);
+            v0 = row_frag_global(qb + 2 * W, ld, jt, 0, lane, S); v1 = row_frag_global(qb + 2 * W, ld, jt, 1, lane, S);
+        }
+        f32x4 dv[4], dk[4];
+        pass2(jt, k0, k1, v0, v1, 0, 1, dk, dv);
+        const int j = jt * 16 + c16;
         if (j < S) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -826,8 +857,30 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_long3_kernel(const bf16_t* qk
         }
         if (cs_part) { cs_tile_to_lds(red + wave * 192 + 64, dk, j < S, c16, g); cs_tile_to_lds(red + wave * 192 + 128, dv, j < S, c16, g); }
     }
+    if (lone && wave < CW) {   // this wave's share of the lone key row
+        k0 = row_frag_global(qb + W, ld, n_t - 1, 0, lane, S); k1 = row_frag_global(qb + W, ld, n_t - 1, 1, lane, S);
+        v0 = row_frag_global(qb + 2 * W, ld, n_t - 1, 0, lane, S); v1 = row_frag_global(qb + 2 * W, ld, n_t - 1, 1, lane, S);
+        f32x4 dv[4], dk[4];
+        pass2(n_t - 1, k0, k1, v0, v1, wave, CW, dk, dv);
+        if (c16 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(f32x4*)(part + wave * 128 + 16 * dt + 4 * g) = dk[dt];
+                *(f32x4*)(part + wave * 128 + 64 + 16 * dt + 4 * g) = dv[dt];
+            }
+        }
+    }
+    if (lone || cs_part) __syncthreads();
+    if (lone && tid < 128) {   // the lone key row: dk (threads 0 .. 63, wave 0) and dv (64 .. 127, wave 1), partial rows in wave order
+        float v = part[tid];
+#pragma unroll
+        for (int w2 = 1; w2 < CW; ++w2) v += part[w2 * 128 + tid];
+        const bf16_t o = f32_to_bf16(v);
+        dqb[(int64_t)(S - 1) * ld + W + (tid >> 6) * W + (tid & 63)] = o;
+        if (cs_part) red[(tid >> 6) * 192 + 64 + tid] += bf16_to_f32(o);   // each into its own wave's row: columns 64 + tid (dk), 128 + tid - 64 (dv)
+    }
     if (cs_part) {   // the waves' sums over their tiles -> the head's 192 columns for image b, waves added in a fixed order
-        __syncthreads();
+        if (lone) __syncthreads();
         if (tid < 192) {
             float v = red[tid];
 #pragma unroll
@@ -917,7 +970,7 @@ int launch_bwd_long2(const void* qkv, const void* d_out, void* d_qkv, int64_t ba
 template <int NT>
 int launch_bwd_long3(const void* qkv, const void* d_out, void* d_qkv, int64_t batch, int64_t seq, int64_t width, int64_t heads, int causal, float* cs_part,
                      hipStream_t st, const void* fwd_out, const float* lse) {
-    const size_t lds = ((size_t)2 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)2 * NT * 16 * sizeof(float) + (size_t)8 * 192 * sizeof(float);
+    const size_t lds = ((size_t)2 * NT * 16 * LDR) * sizeof(bf16_t) + (size_t)2 * NT * 16 * sizeof(float) + (size_t)8 * 192 * sizeof(float) + (size_t)4 * 128 * sizeof(float);
     const dim3 grid((unsigned)(batch * heads));
     if (causal) {
         SC_TRY(reserve_lds(attn_bwd_long3_kernel<NT, true>, lds));
@@ -972,7 +1025,7 @@ int sc_attention_long_bwd(const void* qkv, const void* d_out, void* d_qkv, int64
     static const bool old_long = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG_BWD"); return e && e[0] == '1'; }();   // =1: the register-resident variant (A/B)
     if (old_long) return launch_bwd_block<NT_LONG, 4>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st);
     const bool stats = fwd_out && lse && sc_attention_long_uses_stats(seq);
-    static const bool one_phase = [] { const char* e = getenv("SC_ATTENTION_LONG3"); return e && e[0] == '0'; }();   // =0: all four images in LDS, one workgroup per CU (A/B)
+    static const bool one_phase = [] { const char* e = sc_debug_env("SC_ATTENTION_LONG3"); return e && e[0] == '0'; }();   // =0: all four images in LDS, one workgroup per CU (A/B)
     if (stats && !one_phase) return launch_bwd_long3<NT_LONG>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st, fwd_out, lse);
     return launch_bwd_long2<NT_LONG, 8>(qkv, d_out, d_qkv, batch, seq, width, heads, causal, cs_part, st, stats ? fwd_out : nullptr, stats ? lse : nullptr);
 }
