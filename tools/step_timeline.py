@@ -42,3 +42,23 @@ by_q = collections.defaultdict(float)
 for s, e, n, q in step:
     by_q[q] += (e - s) / 1e6
 print("busy time per hardware queue (ms):", {k: round(v, 2) for k, v in sorted(by_q.items())})
+# what runs while NO bf16 GEMM is in flight: exposed time per kernel class (a moment with several such kernels is split between them)
+active2, last, exposed = collections.Counter(), t0, collections.defaultdict(float)
+names = collections.defaultdict(collections.Counter)
+live = []
+for t, d, c in pts2:
+    if active2["gemm_bf16_nt"] + active2["gemm_bf16_tn"] == 0 and t > last:
+        others = [k for k, v in active2.items() if v > 0]
+        if others:
+            for k in others:
+                exposed[k] += (t - last) / 1e6 / len(others)
+        else:
+            exposed["(nothing running)"] += (t - last) / 1e6
+    active2[c] += d
+    last = t
+print("time with no bf16 GEMM in flight, by what runs instead (ms):", {k: round(v, 2) for k, v in sorted(exposed.items(), key=lambda kv: -kv[1])})
+other = collections.defaultdict(float)
+for s, e, n, q in step:
+    if cls(n) == "other":
+        other[n.replace("(anonymous namespace)::", "").replace("void ", "")[:60]] += (e - s) / 1e6
+print("'other' kernels by summed duration (ms):", {k: round(v, 2) for k, v in sorted(other.items(), key=lambda kv: -kv[1])[:14]})
