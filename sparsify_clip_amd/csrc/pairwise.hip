@@ -310,18 +310,241 @@ __global__ __launch_bounds__(512, 2) void pair_kernel(PairParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ finalisation kernels
-// LSE over the partials of one row / column: out[i] = log sum_k s_k exp(m_k)
-__global__ __launch_bounds__(256) void lse_final_kernel(const float* pm, const float* ps, int parts, int B, float* out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B) return;
-    float m = -INFINITY;
-    for (int k = 0; k < parts; ++k) m = fmaxf(m, pm[(int64_t)k * B + i]);
-    float s = 0.f;
-    for (int k = 0; k < parts; ++k) {
-        const float mk = pm[(int64_t)k * B + i];
-        if (mk > -INFINITY) s += ps[(int64_t)k * B + i] * __expf(mk - m);
+// ------------------------------------------------------------------------------------------------ gradient sweeps at E = 512
+// The kernel above moves 384 KiB from L2 per 64 x 64 tile pair (the X slices again for every column tile, the Y slices, Z^T fragments from
+// global) - twice what a CU can pull in the time its MFMAs need - behind 18 barriers.  Here, for the embedding width of ViT-B/32:
+//   * the wave's 16 rows of X live in registers as MFMA fragments (hi and lo: 128 registers), loaded once per sweep;
+//   * a column tile is 32 rows of Y over the WHOLE width, brought by LDS-DMA (one instruction per 1 KiB row, rows padded to 1056 B: the
+//     16-byte row reads of the first product and the transposed reads of the second are both conflict-free) - 64 KiB per 64 x 32 pair;
+//   * Z = Y in every mode of the loss head, so the second product reads its A operand (Z^T) out of the SAME image with
+//     ds_read_b64_tr_b16; its k-slots are rows {4g .. 4g+3, 16+4g .. 16+4g+3}, and the P fragment is read from its LDS tile in that order;
+//   * three barriers per column tile.  78 KiB of LDS, two workgroups per CU.
+constexpr int GE = 512, GJ = 32, LDY = GE + 16, LDQ = 40;   // LDS row strides in elements: Y 1056 B, P 80 B
+typedef __attribute__((address_space(3))) bf16x4* pair_ltr_t;
+typedef const __attribute__((address_space(1))) void* pair_gptr_t;
+typedef __attribute__((address_space(3))) void* pair_lptr_t;
+
+// (A second Y buffer - the next column tile arriving under this one's arithmetic, 146 KiB, one workgroup per CU - measured the same as this
+// form, where two workgroups per CU cover each other's waits: 2.30 vs 2.25 ms for the experiment_6 stack at B = 8192.)
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void pair_grad512_kernel(PairParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ysm[2 * GJ * LDY];
+    __shared__ __attribute__((aligned(16))) bf16_t psm[2 * PT * LDQ];
+    __shared__ float xrow[2][PT];
+    __shared__ float xred[8];
+    bf16_t* Ph = psm; bf16_t* Pl = psm + PT * LDQ;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int it = blockIdx.x, split = blockIdx.y;
+    const int i0 = it * PT;
+    const int Bi = p.Bi, Bj = p.Bj;
+    const int j_begin = split * p.jt_per_split * PT, j_end = min(Bj, j_begin + p.jt_per_split * PT);
+    const int i_lane = i0 + 16 * wr + c16;
+    float rowc = 0.f;
+    if (MODE == PM_CON_GRAD || MODE == PM_UNIF) rowc = p.rowv[i_lane];
+    bf16x8 xh[GE / 32], xl[GE / 32];
+#pragma unroll
+    for (int ks = 0; ks < GE / 32; ++ks) {
+        xh[ks] = *(const bf16x8*)(p.xh + (int64_t)i_lane * GE + 32 * ks + 8 * g);
+        xl[ks] = *(const bf16x8*)(p.xl + (int64_t)i_lane * GE + 32 * ks + 8 * g);
     }
+    f32x4 oacc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) oacc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rsum = 0.f, scal = 0.f;
+
+    auto bring = [&](int j0, bf16_t* yh, bf16_t* yl) {       // wave w: rows 4 w .. 4 w + 3, hi and lo: one 1 KiB row per LDS-DMA instruction
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wave + q;
+            __builtin_amdgcn_global_load_lds((pair_gptr_t)(p.yh + (int64_t)(j0 + r) * GE + lane * 8), (pair_lptr_t)(yh + r * LDY), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pair_gptr_t)(p.yl + (int64_t)(j0 + r) * GE + lane * 8), (pair_lptr_t)(yl + r * LDY), 16, 0, 0);
+        }
+    };
+    bf16_t* Yh = ysm; bf16_t* Yl = ysm + GJ * LDY;
+    for (int j0 = j_begin; j0 < j_end; j0 += GJ) {
+        f32x4 colc = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == PM_CON_GRAD || MODE == PM_UNIF) colc = *(const f32x4*)(p.colv + j0 + 16 * wc + 4 * g);
+        __syncthreads();                                       // the previous tile's readers of Y and P are done
+        bring(j0, Yh, Yl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- first product: S'[j][i], this wave's 16 columns j0 + 16 wc .. over K = E; one accumulator per term (hi hi, lo hi, hi lo)
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;   // (an MFMA that accumulates into the previous one's result waits for it: rotate)
+#pragma unroll
+        for (int ks = 0; ks < GE / 32; ++ks) {
+            const int fo = (16 * wc + c16) * LDY + 32 * ks + 8 * g;
+            const bf16x8 bh = *(const bf16x8*)(Yh + fo), bl = *(const bf16x8*)(Yl + fo);
+            s0 = PMFMA(bh, xh[ks], s0);
+            s1 = PMFMA(bl, xh[ks], s1);
+            s2 = PMFMA(bh, xl[ks], s2);
+        }
+        // ---- elementwise map: lane = row i_lane, columns j = j0 + 16 wc + 4 g + r
+        f32x4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool dg = i_lane + p.diag_off == j0 + 16 * wc + 4 * g + r;
+            const float sv = s0[r] + (s1[r] + s2[r]);
+            float v;
+            if (MODE == PM_CON_GRAD) {
+                const float l = sv * p.inv_temp;
+                v = p.coef_row * __expf(l - rowc) + p.coef_col * __expf(l - colc[r]) - (dg ? p.coef_diag : 0.f);
+                scal += v * l;
+            } else if (MODE == PM_UNIF) {
+                v = dg ? 0.f : __expf(-p.t * fmaxf(rowc + colc[r] - 2.f * sv, 0.f));
+                rsum += v;
+            } else {
+                v = sv - (dg ? 1.f : -1.f);
+                scal += v * v;
+            }
+            pv[r] = v;
+        }
+        {
+            float r0, r1, r2, r3;
+            uint2 h, l;
+            h.x = pack_hi(pv[0], pv[1], r0, r1); h.y = pack_hi(pv[2], pv[3], r2, r3);
+            l.x = pack2(r0, r1); l.y = pack2(r2, r3);
+            const int po = (16 * wr + c16) * LDQ + 16 * wc + 4 * g;
+            *(uint2*)(Ph + po) = h; *(uint2*)(Pl + po) = l;
+        }
+        __syncthreads();                                       // P complete
+        // ---- second product: O'[e][i] += Z^T[e][j] P[i][j], this wave's output columns e = 64 wave ..; the P fragments of the four row tiles
+        // are read once and held (every wave reads the whole P tile), the Z^T fragments once per 16 output columns
+        bf16x8 ph[4], pl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ao = (16 * a + c16) * LDQ + 4 * g;   // row i = 16 a + c16: columns 4 g .. 4 g + 3 and 16 + 4 g .. (the k-slots of the transposed read)
+            const bf16x4 ph0 = *(const bf16x4*)(Ph + ao), ph1 = *(const bf16x4*)(Ph + ao + 16);
+            const bf16x4 pl0 = *(const bf16x4*)(Pl + ao), pl1 = *(const bf16x4*)(Pl + ao + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ph[a][e] = ph0[e]; ph[a][4 + e] = ph1[e]; pl[a][e] = pl0[e]; pl[a][4 + e] = pl1[e]; }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int zo = (4 * g + (c16 >> 2)) * LDY + 64 * wave + 16 * n + 4 * (c16 & 3);   // this lane's 8-byte piece of the transposed read
+            const bf16x4 zh0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pair_ltr_t)(Yh + zo)), zh1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pair_ltr_t)(Yh + zo + 16 * LDY));
+            const bf16x4 zl0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pair_ltr_t)(Yl + zo)), zl1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pair_ltr_t)(Yl + zo + 16 * LDY));
+            bf16x8 zh, zl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { zh[e] = zh0[e]; zh[4 + e] = zh1[e]; zl[e] = zl0[e]; zl[4 + e] = zl1[e]; }
+            // the three terms of an output tile four MFMAs apart (an MFMA that accumulates into the previous one's result waits for it)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) oacc[a][n] = PMFMA(zh, ph[a], oacc[a][n]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) oacc[a][n] = PMFMA(zl, ph[a], oacc[a][n]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) oacc[a][n] = PMFMA(zh, pl[a], oacc[a][n]);
+        }
+    }
+    // ---- outputs of the sweep: O partial, row-sum partial, scalar partial (as pair_kernel)
+    float* od = p.opart + ((int64_t)split * Bi + i0) * GE + wave * 64;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) *(f32x4*)(od + (int64_t)(16 * a + c16) * GE + 16 * n + 4 * g) = oacc[a][n];
+    if (MODE == PM_UNIF) {
+        rsum += __shfl_xor(rsum, 16, 64);
+        rsum += __shfl_xor(rsum, 32, 64);
+        __syncthreads();
+        if (g == 0) xrow[wc][16 * wr + c16] = rsum;
+        __syncthreads();
+        if (t < PT) p.spart[(int64_t)split * Bi + i0 + t] = xrow[0][t] + xrow[1][t];
+    } else {
+        scal = wave_sum(scal);
+        __syncthreads();
+        if (lane == 0) xred[wave] = scal;
+        __syncthreads();
+        if (t == 0) p.scal_part[it * p.nsplit + split] = ((xred[0] + xred[1]) + (xred[2] + xred[3])) + ((xred[4] + xred[5]) + (xred[6] + xred[7]));
+    }
+}
+
+// Row statistics of the logits at E = 512 (same operand handling as pair_grad512_kernel, first product only): every lane carries the
+// running (max, sum exp) of its row over its columns through the whole sweep, so a workgroup leaves ONE partial per row and split -
+// rp_m / rp_s [nsplit][Bi] - and no column statistics: the column LSE of the square problem is the row LSE of the transposed one (a
+// second sweep of half a gradient sweep's MFMA work, against the 32 cross-lane exchanges per column tile of pair_kernel<PM_CON_STATS>).
+__global__ __launch_bounds__(512, 2) void pair_stats512_kernel(PairParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ysm[2 * GJ * LDY];
+    __shared__ float xm[2][PT], xs[2][PT];
+    bf16_t* Yh = ysm; bf16_t* Yl = ysm + GJ * LDY;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int it = blockIdx.x, split = blockIdx.y;
+    const int i0 = it * PT;
+    const int Bi = p.Bi, Bj = p.Bj;
+    const int j_begin = split * p.jt_per_split * PT, j_end = min(Bj, j_begin + p.jt_per_split * PT);
+    const int i_lane = i0 + 16 * wr + c16;
+    bf16x8 xh[GE / 32], xl[GE / 32];
+#pragma unroll
+    for (int ks = 0; ks < GE / 32; ++ks) {
+        xh[ks] = *(const bf16x8*)(p.xh + (int64_t)i_lane * GE + 32 * ks + 8 * g);
+        xl[ks] = *(const bf16x8*)(p.xl + (int64_t)i_lane * GE + 32 * ks + 8 * g);
+    }
+    float m = -INFINITY, sum = 0.f;
+    for (int j0 = j_begin; j0 < j_end; j0 += GJ) {
+        __syncthreads();                                       // the previous tile's readers are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wave + q;
+            __builtin_amdgcn_global_load_lds((pair_gptr_t)(p.yh + (int64_t)(j0 + r) * GE + lane * 8), (pair_lptr_t)(Yh + r * LDY), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pair_gptr_t)(p.yl + (int64_t)(j0 + r) * GE + lane * 8), (pair_lptr_t)(Yl + r * LDY), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+#pragma unroll
+        for (int ks = 0; ks < GE / 32; ++ks) {
+            const int fo = (16 * wc + c16) * LDY + 32 * ks + 8 * g;
+            const bf16x8 bh = *(const bf16x8*)(Yh + fo), bl = *(const bf16x8*)(Yl + fo);
+            s0 = PMFMA(bh, xh[ks], s0);
+            s1 = PMFMA(bl, xh[ks], s1);
+            s2 = PMFMA(bh, xl[ks], s2);
+        }
+        float v[4], mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = (s0[r] + (s1[r] + s2[r])) * p.inv_temp;
+            mt = fmaxf(mt, v[r]);
+            if (p.diag && i_lane + p.diag_off == j0 + 16 * wc + 4 * g + r) p.diag[i_lane] = v[r];
+        }
+        const float mn = fmaxf(m, mt);                         // finite: mt is
+        sum = sum * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));
+        m = mn;
+    }
+    // the four lane groups of a row, then the two column halves, in a fixed order
+    lse_merge(m, sum, __shfl_xor(m, 16, 64), __shfl_xor(sum, 16, 64));
+    lse_merge(m, sum, __shfl_xor(m, 32, 64), __shfl_xor(sum, 32, 64));
+    if (g == 0) { xm[wc][16 * wr + c16] = m; xs[wc][16 * wr + c16] = sum; }
+    __syncthreads();
+    if (t < PT) {
+        float m0 = xm[0][t], s0 = xs[0][t];
+        lse_merge(m0, s0, xm[1][t], xs[1][t]);
+        p.rp_m[(int64_t)split * Bi + i0 + t] = m0; p.rp_s[(int64_t)split * Bi + i0 + t] = s0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ finalisation kernels
+// LSE over the partials of one row / column: out[i] = log sum_k s_k exp(m_k).  32 outputs per workgroup, the partials of an output dealt
+// to 8 threads (merged on-line, then in slice order through LDS): one thread per output walked 128 partials 32 KiB apart on 32 workgroups
+// (95 us at B = 8192, twice per contrastive term).
+constexpr int LSE_OUT = 32;   // outputs per workgroup of lse_final_kernel
+__global__ __launch_bounds__(256) void lse_final_kernel(const float* pm, const float* ps, int parts, int B, float* out) {
+    __shared__ float sm_m[8][LSE_OUT], sm_s[8][LSE_OUT];
+    const int tx = threadIdx.x & (LSE_OUT - 1), ty = threadIdx.x / LSE_OUT;
+    const int i = blockIdx.x * LSE_OUT + tx;
+    float m = -INFINITY, s = 0.f;
+    if (i < B)
+        for (int k = ty; k < parts; k += 8) lse_merge(m, s, pm[(int64_t)k * B + i], ps[(int64_t)k * B + i]);
+    sm_m[ty][tx] = m; sm_s[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || i >= B) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) lse_merge(m, s, sm_m[k][tx], sm_s[k][tx]);
     out[i] = m + logf(s);
 }
 // out = scale * sum_s part[s]   (fixed order), n elements
@@ -387,9 +610,22 @@ static void pair_carve(void* ws, int64_t b, int64_t e, PairWs& w) {
 
 bool sc_pair_supported(int64_t b, int64_t e) { return b >= 2 * PT && b % PT == 0 && e % 128 == 0 && e >= 128 && e <= 1024 && b <= 65536; }
 
+static bool pair_wide_off() {
+    static const bool off = [] { const char* e = sc_debug_env("SC_PAIR_OLD"); return e && e[0] == '1'; }();   // =1: the sliced kernel at every width (A/B)
+    return off;
+}
+static bool pair_stats512(const PairParams& p) { return p.E == GE && !pair_wide_off(); }
+
 template <int MODE>
 static int pair_launch(const PairParams& p, hipStream_t st) {
     const dim3 grid((unsigned)(p.Bi / PT), (unsigned)p.nsplit);
+    if constexpr (MODE != PM_CON_STATS) {
+        if (p.E == GE && !pair_wide_off()) {   // column tiles of 32 rows: Bj % 64 == 0 (sc_pair_supported) covers it
+            hipLaunchKernelGGL((pair_grad512_kernel<MODE>), grid, dim3(512), 0, st, p);
+            SC_CHECK_LAUNCH();
+            return SC_OK;
+        }
+    }
     switch (p.E / 128) {
 #define CASE(N) case N: hipLaunchKernelGGL((pair_kernel<MODE, N>), grid, dim3(512), 0, st, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -417,10 +653,21 @@ int sc_pair_contrastive(const float* img, const float* txt, int64_t b, int64_t e
     p.xh = w.xh; p.xl = w.xl; p.yh = w.yh; p.yl = w.yl; p.Bi = p.Bj = (int)b; p.E = (int)e; p.inv_temp = inv_temp;
     p.nsplit = pair_nsplit(b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
     p.rp_m = w.rp_m; p.rp_s = w.rp_s; p.cp_m = w.cp_m; p.cp_s = w.cp_s; p.diag = diag;
-    SC_TRY(pair_launch<PM_CON_STATS>(p, st));
-    const int parts = (int)(b / PT);
-    hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, 256)), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)b, rowv);
-    hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, 256)), dim3(256), 0, st, w.cp_m, w.cp_s, parts, (int)b, colv);
+    static const bool two_sweeps = [] { const char* e = sc_debug_env("SC_PAIR_STATS2"); return e && e[0] == '1'; }();   // (A/B: 2.18 vs 2.13 ms for the experiment_6 stack)
+    if (two_sweeps && pair_stats512(p)) {   // rows-only statistics: the column LSE is the row LSE of the transposed problem
+        const dim3 grid((unsigned)(b / PT), (unsigned)p.nsplit);
+        hipLaunchKernelGGL(pair_stats512_kernel, grid, dim3(512), 0, st, p);
+        hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, LSE_OUT)), dim3(256), 0, st, w.rp_m, w.rp_s, p.nsplit, (int)b, rowv);
+        PairParams q = p;
+        q.xh = w.yh; q.xl = w.yl; q.yh = w.xh; q.yl = w.xl; q.diag = nullptr;
+        hipLaunchKernelGGL(pair_stats512_kernel, grid, dim3(512), 0, st, q);
+        hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, LSE_OUT)), dim3(256), 0, st, w.rp_m, w.rp_s, p.nsplit, (int)b, colv);
+    } else {
+        SC_TRY(pair_launch<PM_CON_STATS>(p, st));
+        const int parts = (int)(b / PT);
+        hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, LSE_OUT)), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)b, rowv);
+        hipLaunchKernelGGL(lse_final_kernel, dim3((unsigned)sc_cdiv(b, LSE_OUT)), dim3(256), 0, st, w.cp_m, w.cp_s, parts, (int)b, colv);
+    }
     SC_CHECK_LAUNCH();
     if (!grad) return SC_OK;
     // G = gs [ (exp(L - r_i) + exp(L - c_j)) / (2B) - delta_ij / B ];  dI = G T / temp,  dT = G^T I / temp
@@ -506,13 +753,17 @@ int sc_pair_contrastive_rows_stats(const float* img, const float* txt, int64_t b
     p.nsplit = pair_nsplit_rows(bm, b); p.jt_per_split = (int)sc_cdiv(b / PT, p.nsplit);
     p.rp_m = w.rp_m; p.rp_s = w.rp_s; p.cp_m = w.cp_m; p.cp_s = w.cp_s;
     const int parts = (int)(b / PT);
-    const unsigned fb = (unsigned)sc_cdiv(bm, 256);
+    const unsigned fb = (unsigned)sc_cdiv(bm, LSE_OUT);
     p.xh = w.xh + row0 * e; p.xl = w.xl + row0 * e; p.yh = w.yh; p.yl = w.yl; p.diag = diag_rows;          // rows = my images, columns = all texts
-    SC_TRY(pair_launch<PM_CON_STATS>(p, st));
-    hipLaunchKernelGGL(lse_final_kernel, dim3(fb), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)bm, r_rows);
+    const bool s512 = pair_stats512(p);
+    const dim3 grid((unsigned)(bm / PT), (unsigned)p.nsplit);
+    if (s512) hipLaunchKernelGGL(pair_stats512_kernel, grid, dim3(512), 0, st, p);
+    else SC_TRY(pair_launch<PM_CON_STATS>(p, st));
+    hipLaunchKernelGGL(lse_final_kernel, dim3(fb), dim3(256), 0, st, w.rp_m, w.rp_s, s512 ? p.nsplit : parts, (int)bm, r_rows);
     p.xh = w.yh + row0 * e; p.xl = w.yl + row0 * e; p.yh = w.xh; p.yl = w.xl; p.diag = nullptr;            // rows = my texts, columns = all images
-    SC_TRY(pair_launch<PM_CON_STATS>(p, st));
-    hipLaunchKernelGGL(lse_final_kernel, dim3(fb), dim3(256), 0, st, w.rp_m, w.rp_s, parts, (int)bm, c_rows);
+    if (s512) hipLaunchKernelGGL(pair_stats512_kernel, grid, dim3(512), 0, st, p);
+    else SC_TRY(pair_launch<PM_CON_STATS>(p, st));
+    hipLaunchKernelGGL(lse_final_kernel, dim3(fb), dim3(256), 0, st, w.rp_m, w.rp_s, s512 ? p.nsplit : parts, (int)bm, c_rows);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
