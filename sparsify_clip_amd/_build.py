@@ -21,6 +21,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-spill-vgpr-to-agpr=0: two GEMM kernels own the AGPRs (accumulators named directly in inline assembly); the register
 # allocator must never use them as VGPR spill space (csrc/gemm_bf16.hip, audited by _asm_check.py)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+# SC_EXTRA_HIPCC_FLAGS="-DSC_DEBUG_KNOBS": a diagnostic build in which the closed A/B knobs (sc_debug_env) read the environment again;
+# use with --force, and rebuild without it before committing to a measurement
+FLAGS += os.environ.get("SC_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _newer(target: str, deps) -> bool:
