@@ -15,6 +15,8 @@
 // for occupancy).  Per column tile: S[64,64] over K = E in 64-wide slices staged through LDS (hi and lo of both operands);
 // f(S) is written to LDS as a bf16 hi/lo pair (the A operand of the second product); O[64,E] += P[64,64] Z_j[64,E] with every wave
 // owning E/8 output columns and reading its rows of Z^T (a [E,B] copy made once per call) straight from global memory.
+// At E = 512 (ViT-B/32) the gradient sweeps and the row-block statistics take the kernels further down instead (pair_grad512_kernel,
+// pair_stats512_kernel): X fragments in registers, whole-width Y tiles by LDS-DMA, Z read transposed from the same LDS image.
 #include "common.h"
 #include <stdlib.h>
 
