@@ -1566,6 +1566,8 @@ int sc_num_cus() {
     static const int n = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        const char* e = sc_debug_env("SC_GEMM_CUS");   // A/B: persistent grids of fewer workgroups (round 3: 256 -> 128 CUs per launch changes the step by +2 %)
+        if (e && atoi(e) >= 8) cus = atoi(e);
         return (cus / 8) * 8;
     }();
     return n;
