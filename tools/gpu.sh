@@ -20,6 +20,10 @@
 #                                                         -> gpurun_out/bench_c2|c3|c5|fp32|rn50.json
 #   corun        tools/corun_bench.py: the persistent NT GEMM with 16 / 32 / 64 CUs taken by another stream, fixed lists vs tile tickets
 #                                                         -> gpurun_out/gemm_corun.txt
+#   tn_group     tools/tn_group_bench.py: the four weight gradients of a block as one grouped TN launch at the step's block shapes -> gpurun_out/tn_group_bench.txt
+#   epi_half     tools/epi_half_chip.py: stamped tiles of the NT epilogues with 0 / 64 / 128 / 192 CUs held by a diagnostic kernel -> gpurun_out/epi_half_chip.txt
+#   pmc_pair     tools/pmc_loss_pair.sh: SQ counter passes on the loss head's pairwise kernels at B = 8192 -> gpurun_out/pmc/loss_pair_counters.txt
+#   timeline     tools/step_timeline.py over the trace of the last `prof` -> gpurun_out/step_timeline.txt
 #   ln           tools/ln_bench.py stand-alone LayerNorm forward / backward rates -> gpurun_out/layernorm_times.txt
 #   pipeline     tools/pipeline_bench.py: the input stage per phase (host assembly, H2D, loader alone, the step fed by the loader) -> gpurun_out/pipeline_bench.txt
 #   dp2s         the same rehearsal in the default strong-scaling form (global batch split over the ranks, shards by micro-batches) -> gpurun_out/dp2s.json
@@ -106,6 +110,14 @@ for task in "$@"; do
       timeout -k 10 300 python tools/ln_bench.py > gpurun_out/layernorm_times.txt 2>&1; rc=$?; cat gpurun_out/layernorm_times.txt; [ $rc = 0 ] || exit $rc ;;
     pipeline)
       timeout -k 10 400 python tools/pipeline_bench.py > gpurun_out/pipeline_bench.txt 2>&1; rc=$?; cat gpurun_out/pipeline_bench.txt; [ $rc = 0 ] || exit $rc ;;
+    tn_group)
+      timeout -k 10 300 python tools/tn_group_bench.py > gpurun_out/tn_group_bench.txt 2>&1; rc=$?; cat gpurun_out/tn_group_bench.txt; [ $rc = 0 ] || exit $rc ;;
+    epi_half)
+      timeout -k 10 400 python tools/epi_half_chip.py > gpurun_out/epi_half_chip.txt 2>&1; rc=$?; cat gpurun_out/epi_half_chip.txt; [ $rc = 0 ] || exit $rc ;;
+    pmc_pair)
+      bash tools/pmc_loss_pair.sh || exit 1 ;;
+    timeline)
+      python3 tools/step_timeline.py gpurun_out/prof/bench_kernel_trace.csv > gpurun_out/step_timeline.txt; rc=$?; cat gpurun_out/step_timeline.txt; [ $rc = 0 ] || exit $rc ;;
     attn)
       timeout -k 10 300 python tools/attn_bench.py > gpurun_out/attention_times.txt 2>&1; rc=$?; cat gpurun_out/attention_times.txt; [ $rc = 0 ] || exit $rc ;;
     *) echo "unknown task $task"; exit 2 ;;

@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/pmc
 export TMPDIR=/tmp
 cd /tmp
