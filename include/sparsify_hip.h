@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 
 enum { SC_OK = 0, SC_ERR_ARG = -1, SC_ERR_SHAPE = -2, SC_ERR_DTYPE = -3, SC_ERR_ALIGN = -4,
        SC_ERR_WORKSPACE = -5, SC_ERR_NO_DEVICE = -6 };
@@ -232,6 +232,12 @@ int sc_text_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* 
 int sc_text_embed_bwd(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted,
                       int64_t batch, int64_t seq, int64_t width, int64_t vocab, float* d_tok_emb, float* d_pos,
                       int accumulate, void* stream);
+/* Index bookkeeping of sc_text_embed_bwd on the device: sorted_keys / order [batch * seq] = the flat positions b * seq + s sorted (stable)
+ * by token id, with key `vocab` for the positions behind a caption's EOT (s > eot[b]: exactly-zero gradient under the causal mask of
+ * open_clip's text tower, ignored by sc_text_embed_bwd).  tokens [batch, seq] contiguous.  ws: sc_token_sort_workspace_bytes(batch * seq, vocab). */
+size_t sc_token_sort_workspace_bytes(int64_t n, int64_t vocab);
+int sc_token_sort(const int64_t* tokens, const int32_t* eot, int64_t batch, int64_t seq, int64_t vocab, int64_t* sorted_keys, int64_t* order,
+                  void* ws, size_t ws_bytes, void* stream);
 /* eot[b] = argmax_s tokens[b,s] (first occurrence)  (text_global_pool 'argmax') */
 int sc_argmax_tokens(const int64_t* tokens, int64_t batch, int64_t seq, int32_t* eot, void* stream);
 /* K10 gather: out[b,:] = x[b*seq + (idx ? idx[b] : 0), :]  (fp32) ; scatter is its adjoint into a ZEROED dx */

@@ -640,13 +640,10 @@ class ClipModel:
         return ops.gemm_f32(b["pooled_ln"], self.param("text_projection"))
 
     def _token_sort(self, tokens, eot, seq):
-        """Sorted token ids + permutation for the token-embedding scatter-add.  Positions after EOT carry an exactly-zero gradient
-        under the causal mask and get the key `vocab` (sorts to the end, ignored by the scatter kernel); no host sync (a
-        .nonzero() would stall the enqueue of the other tower)."""
-        pos_idx = torch.arange(seq, device=self.device, dtype=torch.int32)
-        active = pos_idx[None, :] <= eot[:, None]
-        keys = torch.where(active, tokens, torch.full_like(tokens, self.cfg["vocab"])).reshape(-1)
-        return torch.sort(keys, stable=True)
+        """Sorted token ids + permutation for the token-embedding scatter-add (sc_token_sort: keys and stable radix sort on the device,
+        no host sync - a .nonzero() would stall the enqueue of the other tower).  Positions after EOT carry an exactly-zero gradient
+        under the causal mask and get the key `vocab` (sorts to the end, ignored by the scatter kernel)."""
+        return ops.token_sort(tokens, eot, self.cfg["vocab"])
 
     def text_backward(self, d_emb):
         tw, b = self.text, self.text.bufs

@@ -382,6 +382,17 @@ def text_embed_bwd(dx, sorted_tokens, order, batch, seq, d_tok_emb, d_pos, accum
              int(accumulate), stream_ptr())
 
 
+def token_sort(tokens, eot, vocab):
+    """(sorted_keys, order) of sc_text_embed_bwd for tokens [B, S]: flat positions sorted stably by token id, positions behind the EOT keyed `vocab`."""
+    b, s = tokens.shape
+    n = b * s
+    keys = torch.empty(n, dtype=torch.int64, device=tokens.device)
+    order = torch.empty(n, dtype=torch.int64, device=tokens.device)
+    ws = _workspace(LIB.raw("sc_token_sort_workspace_bytes")(n, vocab), tokens.device, "token_sort")
+    LIB.call("sc_token_sort", ptr(tokens), ptr(eot), b, s, vocab, ptr(keys), ptr(order), ptr(ws), ws.numel(), stream_ptr())
+    return keys, order
+
+
 def argmax_tokens(tokens):
     b, s = tokens.shape
     eot = torch.empty(b, dtype=torch.int32, device=tokens.device)

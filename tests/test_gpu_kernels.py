@@ -564,6 +564,24 @@ def test_attention_bwd_fused_colsum(ops, dtype, seq, heads, causal):
     assert_close(cs2, want.double().sum(0) + 2.0, 1e-5, 1e-4, "attention bwd colsum, accumulate")
 
 
+@pytest.mark.parametrize("batch,seq,vocab", [(37, 77, 49408), (5, 24, 1000), (1024, 77, 49408), (3, 8, 7)])
+def test_token_sort(ops, batch, seq, vocab):
+    """sc_token_sort (index bookkeeping of the token-embedding scatter-add): keys = token id up to the EOT, `vocab` behind it; the result is
+    the stable sort of those keys - bit-equal to torch.sort(stable=True) on the same keys, for ragged captions and repeated tokens."""
+    g = torch.Generator().manual_seed(batch * 1000 + seq)
+    tokens = torch.randint(1, vocab - 1, (batch, seq), generator=g)
+    lengths = torch.randint(1, seq + 1, (batch,), generator=g)
+    for b in range(batch):
+        tokens[b, lengths[b] - 1] = vocab - 1          # the EOT is the largest id (open_clip: argmax pooling)
+        tokens[b, lengths[b]:] = 0
+    eot = (lengths - 1).to(torch.int32)
+    keys, order = ops.token_sort(tokens.to(DEV), eot.to(DEV), vocab)
+    pos = torch.arange(seq)[None, :]
+    want_keys = torch.where(pos <= eot[:, None], tokens, torch.full_like(tokens, vocab)).reshape(-1)
+    wk, wo = torch.sort(want_keys, stable=True)
+    assert torch.equal(keys.cpu(), wk) and torch.equal(order.cpu(), wo)
+
+
 def test_colsum_cast_transpose(ops):
     x = rnd(1000, 2304, seed=61)
     assert_close(ops.colsum(x.to(DEV)), x.double().sum(0), 1e-5, 1e-3, "colsum f32")
