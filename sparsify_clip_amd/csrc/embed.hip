@@ -78,20 +78,73 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* dx, int bat
     }
 }
 
+// one wave per row, four rows per workgroup (a workgroup per 2 KB row spent the kernel's time on dispatching 79 k workgroups: 0.5 ms for 160 MB)
 __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* tokens, const float* tok_emb, const float* pos, int seq, int width,
-                                                             int64_t vocab, float* x) {
-    const int64_t row = blockIdx.x;
-    const int s = (int)(row % seq);
-    int64_t tok = tokens[row];
-    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-    for (int c = threadIdx.x * 4; c < width; c += 1024)
-        *(f32x4*)(x + row * width + c) = *(const f32x4*)(tok_emb + tok * width + c) + *(const f32x4*)(pos + (int64_t)s * width + c);
+                                                             int64_t vocab, int64_t rows, float* x) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int s = (int)(row % seq);
+        int64_t tok = tokens[row];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        for (int c = lane * 4; c < width; c += 256)
+            *(f32x4*)(x + row * width + c) = *(const f32x4*)(tok_emb + tok * width + c) + *(const f32x4*)(pos + (int64_t)s * width + c);
+    }
 }
 
-// one wave per sorted position; only the head of a run of equal tokens works: it adds the run's rows in sorted order.
-// Frequent tokens (start / end of text: one occurrence per caption) make runs of `batch` rows: the run length is found 64
-// positions at a time with a ballot and the rows are fetched 16 at a time (independent loads in flight), added in run order -
-// the same sum, bit for bit, as the one-row-at-a-time loop, without its chain of dependent memory latencies.
+// Token-embedding gradient: d_tok_emb[t] += sum of the dx rows of the positions that hold token t, in a fixed order, no atomics.
+// The positions arrive sorted by token (stable); a run of equal tokens belongs to ONE writer:
+//   * token_scatter_kernel - one wave per sorted position, only the head of a run works; it takes the runs that lie inside one block of 64
+//     sorted positions.  A lane carries all of its column quads (width / 256 of them), 16 rows in flight;
+//   * token_scatter_long_kernel - one workgroup per boundary k = 64 j; the run that crosses k belongs to the FIRST boundary it crosses.
+//     Start-of-text / end-of-text (one per caption) and frequent words make runs of `batch` rows: one wave walked them alone (0.56 ms at
+//     batch 1024, the last kernel of the text tower's backward); here the four waves take every fourth group of 16 rows and their partial
+//     sums are combined through LDS in wave order.
+template <int NC>   // column quads per lane: width <= 256 NC
+__device__ __forceinline__ void token_rows_sum(const float* dx, const int64_t* order, int64_t first, int64_t len, int64_t group0, int64_t gstep, int width,
+                                               int lane, f32x4 (&acc)[NC]) {
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = group0 * 16; k < len; k += gstep * 16) {
+        const int n = (int)min((int64_t)16, len - k);
+        if (n == 16) {
+            f32x4 v[8][NC];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* row = dx + order[first + k + 8 * half + j] * width;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) v[j][q] = (lane * 4 + 256 * q < width) ? *(const f32x4*)(row + lane * 4 + 256 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) acc[q] += v[j][q];
+            }
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const float* row = dx + order[first + k + j] * width;
+#pragma unroll
+                for (int q = 0; q < NC; ++q)
+                    if (lane * 4 + 256 * q < width) acc[q] += *(const f32x4*)(row + lane * 4 + 256 * q);
+            }
+        }
+    }
+}
+
+// length of the run of `tok` that starts at sorted position i (wave-uniform), 64 positions per ballot
+__device__ __forceinline__ int64_t token_run_length(const int64_t* sorted_tokens, int64_t n_sorted, int64_t i, int64_t tok, int lane) {
+    int64_t len = 0;
+    for (int64_t base = i;; base += 64) {
+        const int64_t k = base + lane;
+        const bool same = k < n_sorted && sorted_tokens[k] == tok;
+        const unsigned long long m = __ballot(same);
+        if (m == ~0ull) { len += 64; continue; }
+        return len + __builtin_ctzll(~m);
+    }
+}
+
+template <int NC>
 __global__ __launch_bounds__(256) void token_scatter_kernel(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted,
                                                             int width, int64_t vocab, float* d_tok_emb) {
     const int lane = threadIdx.x & 63;
@@ -100,30 +153,48 @@ __global__ __launch_bounds__(256) void token_scatter_kernel(const float* dx, con
     const int64_t tok = sorted_tokens[i];
     if (i > 0 && sorted_tokens[i - 1] == tok) return;
     if (tok < 0 || tok >= vocab) return;
-    int64_t len = 0;
-    for (int64_t base = i;; base += 64) {
-        const int64_t k = base + lane;
-        const bool same = k < n_sorted && sorted_tokens[k] == tok;
-        const unsigned long long m = __ballot(same);
-        if (m == ~0ull) { len += 64; continue; }
-        len += __builtin_ctzll(~m);
-        break;
+    const int64_t len = token_run_length(sorted_tokens, n_sorted, i, tok, lane);
+    if ((i >> 6) != ((i + len - 1) >> 6)) return;          // crosses a boundary of 64: token_scatter_long_kernel's
+    f32x4 acc[NC];
+    token_rows_sum<NC>(dx, order, i, len, 0, 1, width, lane, acc);
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+        if (lane * 4 + 256 * q < width) *(f32x4*)(d_tok_emb + tok * width + lane * 4 + 256 * q) += acc[q];
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void token_scatter_long_kernel(const float* dx, const int64_t* sorted_tokens, const int64_t* order, int64_t n_sorted,
+                                                                 int width, int64_t vocab, float* d_tok_emb) {
+    __shared__ f32x4 part[3][NC][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k = ((int64_t)blockIdx.x + 1) * 64;      // the boundary between sorted positions k - 1 and k
+    if (k >= n_sorted) return;
+    const int64_t tok = sorted_tokens[k];
+    if (sorted_tokens[k - 1] != tok || tok < 0 || tok >= vocab) return;     // no run crosses this boundary (block-uniform)
+    // the run's start: within the 64 positions in front of k, or further back - then an earlier boundary owns the run
+    const bool same = sorted_tokens[k - 64 + lane] == tok;                  // k >= 64
+    const unsigned long long m = __ballot(same);
+    int64_t start;
+    if (m == ~0ull) {                                                       // all 64 positions in front of k hold the token
+        if (k > 64 && sorted_tokens[k - 65] == tok) return;                 // ... and the one in front of them: the run crosses boundary k - 64 first
+        start = k - 64;
+    } else {
+        start = k - __builtin_clzll(~m);                                    // the highest lane that differs is the position just in front of the run
     }
-    for (int c0 = 0; c0 < width; c0 += 256) {
-        const int c = c0 + lane * 4;
-        if (c >= width) continue;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int64_t k = 0;
-        for (; k + 16 <= len; k += 16) {
-            f32x4 v[16];
+    const int64_t len = (k - start) + token_run_length(sorted_tokens, n_sorted, k, tok, lane);
+    f32x4 acc[NC];
+    token_rows_sum<NC>(dx, order, start, len, wave, 4, width, lane, acc);   // wave w: groups of 16 rows w, w + 4, ...
+    if (wave > 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = *(const f32x4*)(dx + order[i + k + j] * width + c);
+        for (int q = 0; q < NC; ++q) part[wave - 1][q][lane] = acc[q];
+    }
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc += v[j];
-        }
-        for (; k < len; ++k) acc += *(const f32x4*)(dx + order[i + k] * width + c);
-        f32x4* o = (f32x4*)(d_tok_emb + tok * width + c);
-        *o += acc;
+    for (int q = 0; q < NC; ++q) {
+        f32x4 s = acc[q];
+        s += part[0][q][lane]; s += part[1][q][lane]; s += part[2][q][lane];
+        if (lane * 4 + 256 * q < width) *(f32x4*)(d_tok_emb + tok * width + lane * 4 + 256 * q) += s;
     }
 }
 
@@ -277,7 +348,9 @@ extern "C" int sc_vit_tokens_bwd(const float* dx, int64_t batch, int64_t seq, in
 extern "C" int sc_text_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos, int64_t batch, int64_t seq, int64_t width,
                                  int64_t vocab, float* x, void* stream) {
     SC_REQUIRE(tokens && tok_emb && pos && x && batch > 0 && seq > 0 && width % 4 == 0 && vocab > 0, SC_ERR_ARG, "sc_text_embed_fwd: bad argument");
-    hipLaunchKernelGGL(text_embed_fwd_kernel, dim3((unsigned)(batch * seq)), dim3(256), 0, ST(stream), tokens, tok_emb, pos, (int)seq, (int)width, vocab, x);
+    const int64_t rows = batch * seq;
+    const unsigned grid = (unsigned)min((int64_t)16384, sc_cdiv(rows, 4));
+    hipLaunchKernelGGL(text_embed_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), tokens, tok_emb, pos, (int)seq, (int)width, vocab, rows, x);
     SC_CHECK_LAUNCH();
     return SC_OK;
 }
@@ -292,9 +365,18 @@ extern "C" int sc_text_embed_bwd(const float* dx, const int64_t* sorted_tokens, 
     }
     hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)sc_cdiv(width, 64), (unsigned)seq), dim3(256), 0, ST(stream), dx, (int)batch, (int)seq, (int)width,
                        d_pos, (float*)nullptr, accumulate);
-    if (n_sorted > 0)
-        hipLaunchKernelGGL(token_scatter_kernel, dim3((unsigned)sc_cdiv(n_sorted, 4)), dim3(256), 0, ST(stream), dx, sorted_tokens, order, n_sorted, (int)width,
-                           vocab, d_tok_emb);
+    if (n_sorted > 0) {
+        SC_REQUIRE(width <= 1024, SC_ERR_SHAPE, "sc_text_embed_bwd: width %lld > 1024", (long long)width);
+        const dim3 gs((unsigned)sc_cdiv(n_sorted, 4)), gl((unsigned)max((int64_t)1, (n_sorted - 1) / 64));
+#define TOKEN_SCATTER(NC)                                                                                                                             \
+        do {                                                                                                                                          \
+            hipLaunchKernelGGL(token_scatter_kernel<NC>, gs, dim3(256), 0, ST(stream), dx, sorted_tokens, order, n_sorted, (int)width, vocab, d_tok_emb); \
+            if (n_sorted > 64)                                                                                                                        \
+                hipLaunchKernelGGL(token_scatter_long_kernel<NC>, gl, dim3(256), 0, ST(stream), dx, sorted_tokens, order, n_sorted, (int)width, vocab, d_tok_emb); \
+        } while (0)
+        if (width <= 256) TOKEN_SCATTER(1); else if (width <= 512) TOKEN_SCATTER(2); else if (width <= 768) TOKEN_SCATTER(3); else TOKEN_SCATTER(4);
+#undef TOKEN_SCATTER
+    }
     SC_CHECK_LAUNCH();
     return SC_OK;
 }

@@ -663,6 +663,38 @@ def test_text_stem_and_pool(ops):
     assert torch.equal(dxs.cpu(), want.reshape(b * s, w))
 
 
+@pytest.mark.parametrize("batch,seq,width,vocab", [(300, 24, 512, 50), (129, 16, 768, 9), (64, 8, 256, 3), (1024, 32, 512, 49408), (70, 77, 1024, 400)])
+def test_token_scatter_long_runs(ops, batch, seq, width, vocab):
+    """Token-embedding gradient with runs of equal tokens far longer than 64 sorted positions (start / end of text: one per caption; tiny
+    vocabularies): runs inside a block of 64 sorted positions belong to token_scatter_kernel, runs that cross a boundary to
+    token_scatter_long_kernel's workgroup at the first boundary crossed - also when the run starts exactly on a boundary or covers whole
+    blocks.  Against an fp64 index_add; bit-stable run to run; the accumulate form adds."""
+    g = torch.Generator().manual_seed(batch + seq)
+    tokens = torch.randint(1, max(2, vocab - 2), (batch, seq), generator=g)
+    tokens[:, 0] = vocab - 2
+    lengths = torch.randint(2, seq + 1, (batch,), generator=g)
+    for b in range(batch):
+        tokens[b, lengths[b] - 1] = vocab - 1
+        tokens[b, lengths[b]:] = 0
+    eot = (lengths - 1).to(torch.int32)
+    emb, pos = rnd(vocab, width, seed=84), rnd(seq, width, seed=85)
+    x = ops.text_embed_fwd(tokens.to(DEV), emb.to(DEV), pos.to(DEV))
+    assert torch.equal(x.cpu(), (emb[tokens] + pos).reshape(batch * seq, width))
+    active = torch.arange(seq)[None, :] <= eot[:, None]
+    dx = (rnd(batch * seq, width, seed=86).reshape(batch, seq, width) * active[..., None]).reshape(batch * seq, width)
+    keys, order = ops.token_sort(tokens.to(DEV), eot.to(DEV), vocab)
+    d_emb, d_pos = torch.full((vocab, width), 7.0, device=DEV), torch.zeros(seq, width, device=DEV)
+    ops.text_embed_bwd(dx.to(DEV), keys, order, batch, seq, d_emb, d_pos, False)
+    want = torch.zeros(vocab, width, dtype=torch.float64).index_add_(0, tokens.reshape(-1), dx.double())
+    tol = 1e-5 * float(np.sqrt(batch))       # fp32 sums of up to `batch` terms of unit size (the start / end-of-text rows) against fp64
+    assert_close(d_emb, want, 1e-5, tol, "token embedding scatter-add, long runs")
+    again = torch.zeros(vocab, width, device=DEV)
+    ops.text_embed_bwd(dx.to(DEV), keys, order, batch, seq, again, torch.zeros(seq, width, device=DEV), False)
+    assert torch.equal(again, d_emb), "not bit-stable"
+    ops.text_embed_bwd(dx.to(DEV), keys, order, batch, seq, again, torch.zeros(seq, width, device=DEV), True)
+    assert_close(again, 2 * want, 1e-5, 2 * tol, "token embedding scatter-add, accumulate")
+
+
 def test_adamw_matches_torch(ops):
     n = 5003
     p0, g = rnd(n, seed=91), [rnd(n, seed=92 + i, scale=0.1) for i in range(3)]
