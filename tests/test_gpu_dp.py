@@ -120,7 +120,11 @@ def test_dp2_step_equals_dp1_step(model_name, batch, micro):
             assert torch.allclose(proj, want_p, rtol=1e-4, atol=2e-5), (proj - want_p).abs().max()
         else:
             assert torch.allclose(proj, want_p, rtol=1e-4, atol=1e-6)
-        assert torch.allclose(emb, want_e, rtol=1e-4, atol=1e-6)
+        # token embedding: the rows of the start / end-of-text tokens are sums over every caption; two ranks add two half-batch sums where the
+        # single process adds one run of 128 rows (token_scatter_long_kernel: four interleaved partial sums) - after three AdamW steps ONE
+        # element of the table differs by 1.24e-6 (measured when the scatter kernel changed in round 3; the gradient buckets above agree to
+        # 1e-5 of their norm).  2.5e-6 absolute = 2.5e-3 of one AdamW step at this learning rate.
+        assert torch.allclose(emb, want_e, rtol=1e-4, atol=2.5e-6), ((emb - want_e).abs().max(), ((emb - want_e).abs() > 2.5e-6 + 1e-4 * want_e.abs()).sum())
     assert out[0][0] == out[1][0]      # both ranks evaluate the identical global-batch loss
 
 
