@@ -21,6 +21,25 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* img, int res, 
     }
 }
 
+// The same for a compile-time patch size with P % 4 == 0 (ViT-B/32, B/16): four consecutive kx per thread (one 16-byte load, one 8 / 16-byte
+// store) and index arithmetic by constants - the generic kernel spends its time on four run-time integer divisions per element (0.45 ms for
+// the 1024 x 3 x 224 x 224 images of a micro-batch, the first kernel of the image tower).
+template <typename T, int P>
+__global__ __launch_bounds__(256) void im2col_p_kernel(const float* img, int res, int g, int kpad, T* out) {
+    constexpr int KR = 3 * P * P;
+    const int64_t row = blockIdx.x;   // b*g*g + py*g + px
+    const int b = (int)(row / (g * g)), pp = (int)(row % (g * g)), py = pp / g, px = pp % g;
+    const float* src = img + (int64_t)b * 3 * res * res + (int64_t)(py * P) * res + px * P;
+    for (int col = threadIdx.x * 4; col < kpad; col += 1024) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col < KR) {
+            const int c = col / (P * P), rem = col % (P * P), ky = rem / P, kx = rem % P;
+            v = *(const f32x4*)(src + ((int64_t)c * res + ky) * res + kx);
+        }
+        io<T>::st4(out + row * kpad + col, v);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void vit_tokens_fwd_kernel(const T* patch_out, const float* cls, const float* pos, int seq, int width, float* x) {
     const int64_t row = blockIdx.x;   // b*seq + s
@@ -314,6 +333,14 @@ extern "C" int sc_im2col(const float* images, int64_t batch, int64_t res, int64_
     const int g = (int)(res / patch), kreal = (int)(3 * patch * patch);
     SC_REQUIRE(kpad >= kreal, SC_ERR_SHAPE, "sc_im2col: kpad %lld < 3*P*P", (long long)kpad);
     const dim3 grid((unsigned)(batch * g * g));
+    if ((patch == 32 || patch == 16) && kpad % 4 == 0 && res % 4 == 0 && sc_aligned(images, 16) && sc_aligned(out, 16) && (dtype == SC_BF16 || dtype == SC_F32)) {
+#define IM2COL_P(T, P) hipLaunchKernelGGL((im2col_p_kernel<T, P>), grid, dim3(256), 0, ST(stream), images, (int)res, g, (int)kpad, (T*)out)
+        if (dtype == SC_BF16) { if (patch == 32) IM2COL_P(bf16_t, 32); else IM2COL_P(bf16_t, 16); }
+        else { if (patch == 32) IM2COL_P(float, 32); else IM2COL_P(float, 16); }
+#undef IM2COL_P
+        SC_CHECK_LAUNCH();
+        return SC_OK;
+    }
     if (dtype == SC_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), images, (int)res, (int)patch, g, kreal, (int)kpad, (bf16_t*)out);
     else if (dtype == SC_F32) hipLaunchKernelGGL(im2col_kernel<float>, grid, dim3(256), 0, ST(stream), images, (int)res, (int)patch, g, kreal, (int)kpad, (float*)out);
     else return sc_set_error(SC_ERR_DTYPE, "sc_im2col: bad dtype");

@@ -601,12 +601,13 @@ def test_colsum_cast_transpose(ops):
         assert torch.equal(d, t.t().contiguous().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("res,p", [(64, 32), (64, 16), (56, 14)])      # 32 / 16: the vectorised compile-time-P kernel; 14 (ViT-L/14): the generic one
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_vit_stem(ops, dtype):
-    b, res, p, w = 3, 64, 32, 128
+def test_vit_stem(ops, dtype, res, p):
+    b, w = 3, 128
     g = res // p
     img = rnd(b, 3, res, res, seed=71)
-    cols = ops.im2col(img.to(DEV), p, 3 * p * p + 64, dtype)
+    cols = ops.im2col(img.to(DEV), p, (3 * p * p + 64) // 64 * 64, dtype)
     ref = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(b * g * g, 3 * p * p)
     assert torch.equal(cols[:, : 3 * p * p].float().cpu(), ref.to(dtype).float())
     assert not cols[:, 3 * p * p:].any()
