@@ -8,6 +8,11 @@ ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 adam = [e[0] for e in ev if "adamw_kernel" in e[2]]
 big = [t for i, t in enumerate(adam) if i == 0 or t - adam[i - 1] > 5_000_000]     # first adamw launch of each step (151 M params: one big launch)
 t0, t1 = big[-2], big[-1]
+if len(sys.argv) > 2 and sys.argv[2] == "longest":     # the step with the most dispatches (bench.py's default run: the global-batch step, followed by shorter variants)
+    import bisect
+    starts = [e[0] for e in ev]
+    k = max(range(len(big) - 1), key=lambda i: bisect.bisect_left(starts, big[i + 1]) - bisect.bisect_left(starts, big[i]))   # most dispatches
+    t0, t1 = big[k], big[k + 1]
 step = [e for e in ev if t0 <= e[0] < t1]
 print(f"step window {(t1 - t0) / 1e6:.2f} ms, {len(step)} kernel dispatches")
 def cls(n):
