@@ -84,6 +84,27 @@ int check_desc(const sc_block_desc* d, const char* who) {
 
 }  // namespace
 
+namespace {
+// byte offsets of the partial-sum regions of a backward block inside d->ws (deferred reductions: every producer keeps its partials until
+// the block's one reduction launch): c_fc bias gradient (GEMM epilogue: one row per 64 output rows + 2, at least the 1024 rows the GEMM asks
+// for), ln_2 (at most 1024 rows of three sums), in_proj bias gradient (attention backward: one row per image), ln_1
+struct ReduceRegions { size_t fc1, ln2, attn, ln1, total; };
+ReduceRegions reduce_regions(int64_t rows, int64_t batch, int64_t width, int64_t mlp_width) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    ReduceRegions r;
+    const size_t ln = up((size_t)1024 * 3 * width * sizeof(float));
+    size_t fc1 = up((size_t)(rows / 64 + 2) * mlp_width * sizeof(float));
+    const size_t fc1_min = up((size_t)1024 * mlp_width * sizeof(float));
+    if (fc1 < fc1_min) fc1 = fc1_min;
+    r.fc1 = 0;
+    r.ln2 = fc1;
+    r.attn = r.ln2 + ln;
+    r.ln1 = r.attn + up((size_t)(batch > 1024 ? batch : 1024) * 3 * width * sizeof(float));   // one row per image; 1024: what the un-fused column-sum pass may ask for
+    r.total = r.ln1 + ln;
+    return r;
+}
+}  // namespace
+
 extern "C" size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t mlp_width, int dtype) {
     if (rows <= 0 || width <= 0 || mlp_width <= 0) return 0;
     size_t need = (size_t)1024 * 3 * (size_t)width * sizeof(float);                       // LayerNorm partials
@@ -100,6 +121,10 @@ extern "C" size_t sc_block_workspace_bytes(int64_t rows, int64_t width, int64_t 
             const size_t w = sc_gemm_bf16_tn_group_ws(4, gm, gn, rows);
             need = need > w ? need : w;
         }
+    }
+    if (dtype == SC_BF16) {   // the four column-sum producers of a backward block keep their partials side by side until ONE reduction launch
+        const size_t w = reduce_regions(rows, sc_cdiv(rows, 16), width, mlp_width).total;   // sequences of 16 positions or more keep the regions apart
+        need = need > w ? need : w;
     }
     return ((need + 255) / 256) * 256;
 }
@@ -194,12 +219,37 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     static const bool group_env = [] { const char* e = sc_debug_env("SC_BLOCK_DW_GROUP"); return !(e && e[0] == '0'); }();
     const bool fcs_early = bf && [] { const char* e = sc_debug_env("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();
     const bool grouped = group_env && fcs_early && rows % 64 == 0;
+    // Deferred reductions (two-stream bf16 path, workspace permitting): the second stages of the block's column sums - c_fc bias, ln_2,
+    // in_proj bias, ln_1 (+ c_proj bias of the last block) - are recorded while the block is enqueued and launched ONCE at its end; every
+    // producer gets its own region of d->ws for its partials.  (Each of those small launches was a kernel the stream's next kernel waited
+    // for while the other tower's persistent GEMM held the CUs: ~90 us apiece in the step, four per block.)
+    static const bool defer_env = [] { const char* e = sc_debug_env("SC_BLOCK_DEFER_REDUCE"); return !(e && e[0] == '0'); }();
+    const ReduceRegions rr = reduce_regions(rows, d->batch, W, MLP);
+    const bool defer = two && grouped && defer_env && d->ws_bytes >= rr.total;   // grouped: no other reduction of this file is enqueued from here on the side stream
+    ScReduceJobs jobs;
+    struct DeferGuard {   // an early return (SC_TRY) must not leave the thread recording
+        bool on;
+        ~DeferGuard() { if (on) sc_reduce_defer_cancel(); }
+    } guard{defer};
+    if (defer) sc_reduce_defer_begin(&jobs);
+    char* const ws0 = (char*)d->ws;
+    void* const ws_fc1 = defer ? ws0 + rr.fc1 : d->ws;
+    void* const ws_ln2 = defer ? ws0 + rr.ln2 : d->ws;
+    void* const ws_attn = defer ? ws0 + rr.attn : d->ws;
+    void* const ws_ln1 = defer ? ws0 + rr.ln1 : d->ws;
+    const size_t ws_fc1_bytes = defer ? rr.ln2 - rr.fc1 : d->ws_bytes, ws_ln2_bytes = defer ? rr.attn - rr.ln2 : d->ws_bytes;
+    const size_t ws_attn_bytes = defer ? rr.ln1 - rr.attn : d->ws_bytes, ws_ln1_bytes = defer ? rr.total - rr.ln1 : d->ws_bytes;
+
     // ---- MLP half: c_proj, GELU', c_fc
     if (!gate && !grouped) {
         SC_TRY(publish());
         SC_TRY(linear_dw(dt, rows, W, MLP, g, d->h_act, d->g_w_fc2, acc, wsw, wsw_bytes, ss));
     }
-    if (!d->b_fc2_done) SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));   // reads the fp32 dx_out: main stream
+    if (!d->b_fc2_done) {   // the last block only; reads the fp32 dx_out: main stream.  Reduced at once (its partials would share a region with ln_1's)
+        if (defer) sc_reduce_defer_cancel();
+        SC_TRY(sc_colsum(dx_out, SC_F32, rows, W, W, d->g_b_fc2, acc, d->ws, d->ws_bytes, stream));
+        if (defer) sc_reduce_defer_begin(&jobs);
+    }
     static const bool fuse_cs = [] { const char* e = sc_debug_env("SC_BLOCK_FUSE_CS"); return !(e && e[0] == '0'); }();   // =0: separate column-sum passes (A/B runs)
     const bool fcs = bf && fuse_cs;
     EpiParams e = epi_plain();
@@ -207,7 +257,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     if (!ug) {
         e.dgelu_pre = d->h_pre; e.ld_aux = MLP;
         if (fcs) {   // c_fc's bias gradient = column sums of d_h: taken in the epilogue that produces d_h (main stream, main workspace)
-            e.colsum = d->g_b_fc1; e.colsum_ws = d->ws; e.colsum_ws_bytes = d->ws_bytes; e.colsum_accumulate = acc;
+            e.colsum = d->g_b_fc1; e.colsum_ws = ws_fc1; e.colsum_ws_bytes = ws_fc1_bytes; e.colsum_accumulate = acc;
         }
     }
     SC_TRY(linear_dx(dt, rows, W, MLP, g, d->w_fc2, d->wt_fc2, d->d_h, e, st, d->tile_tickets));                 // d_h = (dx_out W2) * gelu'(h_pre)
@@ -222,7 +272,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     // With a side stream the copy must not land in the buffer `g` that the side stream may still be reading (internal-cast case).
     SC_REQUIRE(!(two && bf && g == d->d_res_t), SC_ERR_ARG, "sc_block_bwd_async: pass dx_out_t (the internal cast reuses d_res_t)");
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_mid, d->ln2_mean, d->ln2_rstd, d->ln2_g, rows, W, dx_out, d->dx_mid, bf ? d->d_res_t : nullptr,
-                            d->g_ln2_g, d->g_ln2_b, d->g_b_o, acc, d->ws, d->ws_bytes, stream));
+                            d->g_ln2_g, d->g_ln2_b, d->g_b_o, acc, ws_ln2, ws_ln2_bytes, stream));
     const void* gm = bf ? (const void*)d->d_res_t : (const void*)d->dx_mid;
     // ---- attention half: out_proj, attention, in_proj
     if (!gate && !grouped) {
@@ -241,7 +291,7 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     if (dt == SC_F32 && !sc_attention_f32_bwd_fits_lds(d->seq))   // the one-workgroup-per-head fp32 backward holds S x S scores and dP in LDS
         SC_TRY(sc_attention_f32_composed_bwd((const float*)d->qkv, (const float*)d->d_attn, (float*)d->d_qkv, d->batch, d->seq, W, d->heads, d->causal, d->ws, d->ws_bytes, st));
     else SC_TRY(sc_attention_bwd_stats(d->qkv, d->attn_out, d->attn_lse, d->d_attn, d->d_qkv, dt, d->batch, d->seq, W, d->heads, d->causal, fcs ? d->g_b_qkv : nullptr, acc,
-                                       d->ws, d->ws_bytes, stream));
+                                       ws_attn, ws_attn_bytes, stream));
     SC_TRY(publish());
     if (grouped) {   // dW of c_proj, c_fc, out_proj, in_proj: every operand (g, h_act, d_h, ln2_out, gm, attn_out, d_qkv, ln1_out) is final here
         const int64_t pm[4] = {W, MLP, W, 3 * W}, pn[4] = {MLP, W, W, W};
@@ -256,7 +306,11 @@ int block_bwd_impl(const sc_block_desc* d, const float* dx_out, const void* dx_o
     SC_TRY(linear_dx(dt, rows, 3 * W, W, d->d_qkv, d->w_qkv, d->wt_qkv, d->d_ln, epi_plain(), st, d->tile_tickets));
     // dx_in = dx_mid + LN1'(d_ln)
     SC_TRY(sc_layernorm_bwd(d->d_ln, dt, d->x_in, d->ln1_mean, d->ln1_rstd, d->ln1_g, rows, W, d->dx_mid, dx_in, bf ? dx_in_t : nullptr, d->g_ln1_g,
-                            d->g_ln1_b, d->g_below_b_fc2, acc, d->ws, d->ws_bytes, stream));
+                            d->g_ln1_b, d->g_below_b_fc2, acc, ws_ln1, ws_ln1_bytes, stream));
+    if (defer) {
+        guard.on = false;
+        SC_TRY(sc_reduce_defer_flush(st));
+    }
     return SC_OK;
 }
 

@@ -52,6 +52,24 @@ static inline bool sc_aligned(const void* p, size_t a) { return (((uintptr_t)p) 
 static inline int64_t sc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ----------------------------------------------------------------------------- device helpers
+// Deferred final reductions (layernorm.hip; used by block.hip): between sc_reduce_defer_begin and sc_reduce_defer_flush on the calling thread
+// the second stages of the column-sum producers (LayerNorm backward, the GEMM / attention bias gradients, sc_colsum) are recorded instead
+// of launched, and flush launches them together: one small kernel on the block backward's stream instead of four, each of which the next
+// kernel of the stream would wait for.  The partial buffers must stay untouched until the flush; a job's arithmetic is unchanged.
+constexpr int SC_REDUCE_JOBS = 6;
+struct ScReduceJob {
+    const float* partial;
+    int nblocks, nwhich, width, accumulate, first_block;
+    float *out0, *out1, *out2;
+};
+struct ScReduceJobs {
+    ScReduceJob job[SC_REDUCE_JOBS];
+    int n;
+};
+void sc_reduce_defer_begin(ScReduceJobs* jobs);
+int sc_reduce_defer_flush(hipStream_t st);
+void sc_reduce_defer_cancel();
+
 #ifdef __HIPCC__
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

@@ -8,6 +8,7 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 8;     // width <= 2048
 constexpr int RED_MAX_BLOCKS = 1024; // partial slabs of the column reductions (4 workgroups per CU)
+
 constexpr float LN_EPS = 1e-5f;
 
 // RPW rows per wave: all loads of the wave's rows are issued before the first reduction (memory-level parallelism)
@@ -139,12 +140,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const f
 // out[which][col] (+)= sum_b partial[b][which][col]     (nwhich slabs of `width` columns per block; width % 4 == 0)
 // A workgroup owns 32 consecutive columns of the flattened [nwhich * width] row: 8 threads x 16 bytes across, 32 row groups down;
 // every load is a 16-byte piece of a 128-byte run, the 32 group sums are combined in a fixed order.
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1,
-                                                             float* out2, int accumulate) {
+__device__ __forceinline__ void partial_reduce_body(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1, float* out2,
+                                                    int accumulate, int block) {
     __shared__ f32x4 sm[32][9];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int total = nwhich * width;
-    const int i = (blockIdx.x * 8 + tx) * 4;
+    const int i = (block * 8 + tx) * 4;
     const bool live = i < total;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (live) {
@@ -173,6 +174,20 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partia
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[col + e] = accumulate ? out[col + e] + s[e] : s[e];
     }
+}
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1,
+                                                             float* out2, int accumulate) {
+    partial_reduce_body(partial, nblocks, nwhich, width, out0, out1, out2, accumulate, (int)blockIdx.x);
+}
+// several reductions in ONE launch (sc_reduce_defer_*): workgroup b belongs to the job whose range of blocks holds it; the arithmetic of a job
+// is partial_reduce_kernel's, bit for bit
+__global__ __launch_bounds__(256) void partial_reduce_jobs_kernel(ScReduceJobs jobs) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < SC_REDUCE_JOBS; ++k)
+        if (k < jobs.n && (int)blockIdx.x >= jobs.job[k].first_block) j = k;
+    const ScReduceJob& q = jobs.job[j];
+    partial_reduce_body(q.partial, q.nblocks, q.nwhich, q.width, q.out0, q.out1, q.out2, q.accumulate, (int)blockIdx.x - q.first_block);
 }
 
 // column sums of x [rows, n]: thread = 4 consecutive columns, blockIdx.y = row slab
@@ -224,6 +239,38 @@ __global__ __launch_bounds__(256) void dgelu_mul_colsum_bf16_kernel(bf16_t* dh, 
 
 }  // namespace
 
+// see common.h (ScReduceJobs)
+namespace { thread_local ScReduceJobs* g_reduce_defer = nullptr; }
+void sc_reduce_defer_begin(ScReduceJobs* jobs) { jobs->n = 0; g_reduce_defer = jobs; }
+void sc_reduce_defer_cancel() { g_reduce_defer = nullptr; }
+int sc_reduce_defer_flush(hipStream_t st) {
+    ScReduceJobs* l = g_reduce_defer;
+    g_reduce_defer = nullptr;
+    if (!l || l->n == 0) return SC_OK;
+    int blocks = 0;
+    for (int k = 0; k < l->n; ++k) {
+        l->job[k].first_block = blocks;
+        blocks += (int)sc_cdiv((int64_t)l->job[k].nwhich * l->job[k].width, 32);
+    }
+    hipLaunchKernelGGL(partial_reduce_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *l);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+// the second stage of every column reduction of this file: launched now, or recorded when the calling thread is deferring
+static int launch_partial_reduce(const float* partial, int nblocks, int nwhich, int width, float* out0, float* out1, float* out2, int accumulate, hipStream_t st) {
+    ScReduceJobs* l = g_reduce_defer;
+    if (l && l->n < SC_REDUCE_JOBS) {
+        ScReduceJob& q = l->job[l->n++];
+        q.partial = partial; q.nblocks = nblocks; q.nwhich = nwhich; q.width = width; q.accumulate = accumulate; q.first_block = 0;
+        q.out0 = out0; q.out1 = out1; q.out2 = out2;
+        return SC_OK;
+    }
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv((int64_t)nwhich * width, 32)), dim3(256), 0, st, partial, nblocks, nwhich, width, out0, out1, out2,
+                       accumulate);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+}
+
 // un-fused GELU pieces (A/B experiment against the GEMM epilogues; bf16 only)
 int sc_gelu_fwd_bf16(const void* pre, void* act, int64_t n_elems, hipStream_t st) {
     SC_REQUIRE(pre && act && n_elems > 0 && n_elems % 8 == 0, SC_ERR_ARG, "sc_gelu_fwd_bf16: bad argument");
@@ -239,10 +286,8 @@ int sc_dgelu_mul_colsum_bf16(void* dh, const void* pre, int64_t rows, int64_t n,
     const int nslab = (int)sc_cdiv(rows, rpb);
     hipLaunchKernelGGL(dgelu_mul_colsum_bf16_kernel, dim3((unsigned)sc_cdiv(n, 1024), nslab), dim3(256), 0, st, (bf16_t*)dh, (const bf16_t*)pre, rows, (int)n, rpb,
                        (float*)ws);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 32)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, colsum, (float*)nullptr,
-                       (float*)nullptr, accumulate);
     SC_CHECK_LAUNCH();
-    return SC_OK;
+    return launch_partial_reduce((const float*)ws, nslab, 1, (int)n, colsum, nullptr, nullptr, accumulate, st);
 }
 
 namespace {
@@ -316,19 +361,14 @@ extern "C" int sc_layernorm_bwd(const void* dy, int dtype, const float* x, const
     else { if (nsum == 3) LN_BWD_C(float, 3); else LN_BWD_C(float, 2); }
 #undef LN_BWD_C
 #undef LN_BWD
-    if (dgamma || dbeta || dx_colsum)
-        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(nsum * width, 32)), dim3(256), 0, st, (const float*)ws, nblocks, nsum, (int)width, dgamma,
-                           dbeta, dx_colsum, accumulate);
     SC_CHECK_LAUNCH();
+    if (dgamma || dbeta || dx_colsum) return launch_partial_reduce((const float*)ws, nblocks, nsum, (int)width, dgamma, dbeta, dx_colsum, accumulate, st);
     return SC_OK;
 }
 
 // out[n] (+)= sum over nslab partial rows [nslab][n] (fixed order); second stage of sc_colsum, also used by the GEMM's fused column sums
 int sc_colsum_reduce(const float* partial, int nslab, int64_t n, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 32)), dim3(256), 0, st, partial, nslab, 1, (int)n, out, (float*)nullptr,
-                       (float*)nullptr, accumulate);
-    SC_CHECK_LAUNCH();
-    return SC_OK;
+    return launch_partial_reduce(partial, nslab, 1, (int)n, out, nullptr, nullptr, accumulate, st);
 }
 
 extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int64_t ld, float* out, int accumulate, void* ws, size_t ws_bytes,
@@ -347,8 +387,6 @@ extern "C" int sc_colsum(const void* x, int dtype, int64_t rows, int64_t n, int6
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, rows, (int)n, ld, rpb, (float*)ws);
     else
         return sc_set_error(SC_ERR_DTYPE, "sc_colsum: bad dtype %d", dtype);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)sc_cdiv(n, 32)), dim3(256), 0, st, (const float*)ws, nslab, 1, (int)n, out, (float*)nullptr,
-                       (float*)nullptr, accumulate);
     SC_CHECK_LAUNCH();
-    return SC_OK;
+    return launch_partial_reduce((const float*)ws, nslab, 1, (int)n, out, nullptr, nullptr, accumulate, st);
 }
