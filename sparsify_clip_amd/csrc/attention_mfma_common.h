@@ -41,10 +41,8 @@ static __device__ __forceinline__ bf16x8 row_frag_global(const bf16_t* base, int
 }
 
 static __device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f[e] = (short)f32_to_bf16(lo[e]); f[4 + e] = (short)f32_to_bf16(hi[e]); }
-    return f;
+    const uint4 u = {pack2_bf16(lo[0], lo[1]), pack2_bf16(lo[2], lo[3]), pack2_bf16(hi[0], hi[1]), pack2_bf16(hi[2], hi[3])};   // four v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(bf16x8, u);
 }
 
 // copy a [S][64] bf16 head slice (row stride ld) into an LDS image of NT*16 rows; rows >= S are zero

@@ -296,24 +296,34 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int64_t ld = 3 * (int64_t)W;
     const bf16_t* qb = qkv + (int64_t)b * S * ld + h * HD;
+    // the wave's first query tile: fragments requested in front of the staging; the next tile's under this tile's arithmetic (a query
+    // tile used to start with an exposed round trip to global memory)
+    bf16x8 q0 = row_frag_global(qb, ld, wave, 0, lane, S), q1 = row_frag_global(qb, ld, wave, 1, lane, S);
     stage_head_block(Ks, qb + W, ld, S, NT * 16, tid, 64 * NW);
     stage_head_block(Vs, qb + 2 * W, ld, S, NT * 16, tid, 64 * NW);
     __syncthreads();
     const int g = lane >> 4, c16 = lane & 15;
     const int n_t = (S + 15) >> 4;
     for (int it = wave; it < n_t; it += NW) {
-        const bf16x8 q0 = row_frag_global(qb, ld, it, 0, lane, S), q1 = row_frag_global(qb, ld, it, 1, lane, S);
+        bf16x8 nq0 = q0, nq1 = q1;
+        if (it + NW < n_t) { nq0 = row_frag_global(qb, ld, it + NW, 0, lane, S); nq1 = row_frag_global(qb, ld, it + NW, 1, lane, S); }
         const int i = it * 16 + c16;
         const int jt_end = CAUSAL ? min(n_t, it + 1) : n_t;
+        // Unscaled scores: the maximum commutes with the (positive) scale, and P = 2^((s - max) c) takes one fma and one v_exp per pair.
+        // Only the last key tile (keys beyond the sequence) and, under the causal mask, the diagonal tile hold masked pairs: the others
+        // skip the compare / select.  (Measured VALU-bound: scale, two compares and a select per score in BOTH sweeps, 3 350 vector
+        // instructions per wave against 104 MFMAs.)
+        const float c = scale * 1.4426950408889634f;
         auto scores = [&](int jt) -> f32x4 {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
             a = MFMA16(row_frag_lds(Ks, jt, 0, lane), q0, a);
             a = MFMA16(row_frag_lds(Ks, jt, 1, lane), q1, a);
+            if (jt * 16 + 16 > S || (CAUSAL && jt == it)) {   // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = jt * 16 + 4 * g + r;
-                const bool ok = j < S && (!CAUSAL || j <= i);
-                a[r] = ok ? a[r] * scale : -INFINITY;
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + 4 * g + r;
+                    a[r] = (j < S && (!CAUSAL || j <= i)) ? a[r] : -INFINITY;
+                }
             }
             return a;
         };
@@ -323,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t
             m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
         }
         m = group_max(m);
+        const float nmc = -m * c;
         float l = 0.f;
         f32x4 o[4];
 #pragma unroll
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t
                 const f32x4 a = scores(jt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pr[u][r] = __expf(a[r] - m);   // exp(-inf) = 0 for masked keys
+                    pr[u][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], c, nmc));   // 2^(-inf) = 0 for masked keys
                     l += pr[u][r];
                 }
             }
@@ -357,8 +368,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd_long2_kernel(const bf16_t
             bf16_t* op = out + ((int64_t)b * S + i) * W + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(op + 16 * dt, o[dt] * inv);
-            if (lse && g == 0) lse[(int64_t)blockIdx.x * S + i] = __builtin_amdgcn_logf(inv) - m * 1.4426950408889634f;   // P_ij = 2^(s_ij scale log2 e + lse_i)
+            if (lse && g == 0) lse[(int64_t)blockIdx.x * S + i] = __builtin_amdgcn_logf(inv) + nmc;   // log2(1 / l) - max c: P_ij = 2^(s_ij c + lse_i)
         }
+        q0 = nq0; q1 = nq1;
     }
 }
 

@@ -78,6 +78,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of two bf16 (low half = a): ONE v_cvt_pk_bf16_f32.  Written as (unsigned)f32_to_bf16(a) | (unsigned)f32_to_bf16(b) << 16
+// the compiler emits two conversions, a shift and an or - four vector instructions per pair in epilogues that are bound by the vector ALU.
+typedef __attribute__((ext_vector_type(2))) float sc_f32v2;
+typedef __attribute__((ext_vector_type(2))) __bf16 sc_bf16v2;
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+    const sc_f32v2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sc_bf16v2));
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -99,8 +108,8 @@ template <> struct io<bf16_t> {
     }
     static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
         uint2 u;
-        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        u.x = pack2_bf16(v[0], v[1]);
+        u.y = pack2_bf16(v[2], v[3]);
         *(uint2*)p = u;
     }
 };

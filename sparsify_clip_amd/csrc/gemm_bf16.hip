@@ -369,10 +369,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(GemmBf16Params 
                 *(f32x4*)(cp + 4) = v1;
             } else {
                 uint4 u;
-                u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
-                u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
-                u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
-                u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+                u.x = pack2_bf16(v0[0], v0[1]);
+                u.y = pack2_bf16(v0[2], v0[3]);
+                u.z = pack2_bf16(v1[0], v1[1]);
+                u.w = pack2_bf16(v1[2], v1[3]);
                 *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
             }
         }
@@ -616,10 +616,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(GemmBf16Params
                     if (do_cs) { cs0 += v0; cs1 += v1; }
                 } else {
                     uint4 u;
-                    u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
-                    u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
-                    u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
-                    u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+                    u.x = pack2_bf16(v0[0], v0[1]);
+                    u.y = pack2_bf16(v0[2], v0[3]);
+                    u.z = pack2_bf16(v1[0], v1[1]);
+                    u.w = pack2_bf16(v1[2], v1[3]);
                     *(uint4*)((bf16_t*)p.C + (int64_t)m * p.ldc + n) = u;
                     if (do_cs) {   // the values as stored (bf16-rounded): identical to a pass over C
                         cs0[0] += __uint_as_float(u.x << 16); cs0[1] += __uint_as_float(u.x & 0xffff0000u);
@@ -693,10 +693,10 @@ struct NtpEpi {   // per-tile epilogue context: uniform bases (SGPRs) + this lan
 
 __device__ __forceinline__ uint4 pack8_bf16(const f32x4& v0, const f32x4& v1) {
     uint4 u;
-    u.x = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
-    u.y = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
-    u.z = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
-    u.w = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+    u.x = pack2_bf16(v0[0], v0[1]);
+    u.y = pack2_bf16(v0[2], v0[3]);
+    u.z = pack2_bf16(v1[0], v1[1]);
+    u.w = pack2_bf16(v1[2], v1[3]);
     return u;
 }
 

@@ -211,10 +211,10 @@ __global__ __launch_bounds__(256) void gelu_fwd_bf16_kernel(const bf16_t* pre, b
     const f32x2 c = gelu_fast2(f32x2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)});
     const f32x2 d = gelu_fast2(f32x2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)});
     uint4 o;
-    o.x = (unsigned)f32_to_bf16(a[0]) | ((unsigned)f32_to_bf16(a[1]) << 16);
-    o.y = (unsigned)f32_to_bf16(b[0]) | ((unsigned)f32_to_bf16(b[1]) << 16);
-    o.z = (unsigned)f32_to_bf16(c[0]) | ((unsigned)f32_to_bf16(c[1]) << 16);
-    o.w = (unsigned)f32_to_bf16(d[0]) | ((unsigned)f32_to_bf16(d[1]) << 16);
+    o.x = pack2_bf16(a[0], a[1]);
+    o.y = pack2_bf16(b[0], b[1]);
+    o.z = pack2_bf16(c[0], c[1]);
+    o.w = pack2_bf16(d[0], d[1]);
     *(uint4*)(act + i * 8) = o;
 }
 // dh <- dh * GELU'(pre) in place (bf16), column sums of the result per row slab -> partial [nslab][n]
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void dgelu_mul_colsum_bf16_kernel(bf16_t* dh, 
         const f32x4 v = gelu_grad_mul4(f32x4{__uint_as_float(g.x << 16), __uint_as_float(g.x & 0xffff0000u), __uint_as_float(g.y << 16),
                                              __uint_as_float(g.y & 0xffff0000u)}, h.x, h.y);
         uint2 o;
-        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        o.x = pack2_bf16(v[0], v[1]);
+        o.y = pack2_bf16(v[2], v[3]);
         *(uint2*)(dh + r * n + col) = o;
         s[0] += __uint_as_float(o.x << 16); s[1] += __uint_as_float(o.x & 0xffff0000u);
         s[2] += __uint_as_float(o.y << 16); s[3] += __uint_as_float(o.y & 0xffff0000u);

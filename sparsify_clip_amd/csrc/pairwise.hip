@@ -48,11 +48,11 @@ struct PairParams {
 };
 
 __device__ __forceinline__ unsigned pack_hi(float a, float b, float& ra, float& rb) {   // two bf16 hi parts + the residuals
-    const bf16_t ha = f32_to_bf16(a), hb = f32_to_bf16(b);
-    ra = a - bf16_to_f32(ha); rb = b - bf16_to_f32(hb);
-    return (unsigned)ha | ((unsigned)hb << 16);
+    const unsigned u = pack2_bf16(a, b);
+    ra = a - __uint_as_float(u << 16); rb = b - __uint_as_float(u & 0xffff0000u);
+    return u;
 }
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return pack2_bf16(a, b); }
 
 #define PMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
