@@ -407,9 +407,12 @@ constexpr int B_M = 256, B_N = 256, B_STAGE = (B_M + B_N) * 128, B_A = B_M * 128
     "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
     "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 
-template <int F>
+// ZERO: the tile's first k-step - the accumulator input is the constant 0, so the 128 v_accvgpr_write that cleared the accumulators in front
+// of every tile (on the critical path of every tile but a workgroup's first: its K-tiles are resident when the tile starts) are not needed
+template <int F, bool ZERO = false>
 __device__ __forceinline__ void ntb_mfma(const bf16x8 (&a)[8], const bf16x8 (&b)[4]) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3) : SC_ACC_AGPRS);
+    if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, 0" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3) : SC_ACC_AGPRS);
+    else asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(b[F % 4]), "v"(a[F / 4]), "n"(4 * F), "n"(4 * F + 3) : SC_ACC_AGPRS);
 }
 template <int OFF>
 __device__ __forceinline__ void ntb_read(bf16x8& dst, unsigned base) {
@@ -420,18 +423,18 @@ __device__ __forceinline__ void ntb_read(bf16x8& dst, unsigned base) {
 // a0 b0 a1 b1 a2 b2 a3 b3 a4 a5 a6 a7.  LATE (measured, no gain, not used): enter the sub-step with a4..a7 still in flight
 // (s_waitcnt lgkmcnt(4)); LDS reads return in order, so before group I >= 4 "at most 11 outstanding" proves a[I] has landed.
 // NG = row tiles of the wave (8: 128-row wave tile; 4: the 64-row wave tile of the persistent kernel's half tiles)
-template <int I, bool LOAD, bool LATE = false, int NG = 8>
+template <int I, bool LOAD, bool LATE = false, int NG = 8, bool ZERO = false>
 __device__ __forceinline__ void ntb_substep(bf16x8 (&a)[8], const bf16x8 (&b)[4], bf16x8 (&bn)[4], unsigned abase, unsigned bbase) {
     if constexpr (LATE && I >= 4) {
         if constexpr (LOAD) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(7 - I) : "memory");
     }
-    ntb_mfma<4 * I>(a, b); ntb_mfma<4 * I + 1>(a, b); ntb_mfma<4 * I + 2>(a, b); ntb_mfma<4 * I + 3>(a, b);
+    ntb_mfma<4 * I, ZERO>(a, b); ntb_mfma<4 * I + 1, ZERO>(a, b); ntb_mfma<4 * I + 2, ZERO>(a, b); ntb_mfma<4 * I + 3, ZERO>(a, b);
     if constexpr (LOAD) {
         ntb_read<I * 2048>(a[I], abase);
         if constexpr (I < 4) ntb_read<I * 2048>(bn[I], bbase);
     }
-    if constexpr (I + 1 < NG) ntb_substep<I + 1, LOAD, LATE, NG>(a, b, bn, abase, bbase);
+    if constexpr (I + 1 < NG) ntb_substep<I + 1, LOAD, LATE, NG, ZERO>(a, b, bn, abase, bbase);
 }
 template <int N>
 __device__ __forceinline__ void ntb_zero() {
@@ -902,10 +905,10 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
     // dynamic tile order: wave 0 requests the next tile's ticket with the LDS-DMA of K-tile 0 and publishes it behind K-tile 1's wait
     // (the two K-tiles of one trip of the loop below, so the register is not carried around the loop); nk >= 3, checked by the launcher
     const unsigned box = lds0 + 2 * B_STAGE;
-#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0, HOOK)   /* K-tile KT is not the last one: as NTB_FULL */    \
+#define NTP_FULL(S, KT, A_S1, B_S1, A_N0, B_N0, HOOK, Z)   /* K-tile KT is not the last one: as NTB_FULL; Z: the tile's first k-step */    \
     do {                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
-        ntb_substep<0, true, false, NG>(a, b0, b1, A_S1, B_S1);                                       \
+        ntb_substep<0, true, false, NG, Z>(a, b0, b1, A_S1, B_S1);                                    \
         if ((S) == 0 && (KT) == 0 && !first) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NV) : "memory");   /* K-tile 1 is older than the previous epilogue's stores */ \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
         if ((HOOK) && (S) == 1 && tickets && wave == 0 && (KT) == 1) ntp_ticket_publish(box, ticket); \
@@ -914,7 +917,10 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
         if ((HOOK) && (S) == 0 && tickets && wave == 0 && (KT) == 0) ntp_ticket_request(tickets, ticket); \
         ntb_substep<0, true, false, NG>(a, b1, b0, A_N0, B_N0);                                       \
     } while (0)
-    ntb_zero<0>();
+    // The accumulators start from the constant 0 of the first k-step's MFMAs (peeled first trip below); tiles of one or two K-tiles
+    // clear them by hand
+    const bool peel = nk > 2;
+    if (!peel) ntb_zero<0>();
     // K-tile 0 of this tile: requested in the prologue (first tile: K-tile 1 is the youngest request and may stay in flight)
     // or in front of the previous tile's epilogue (its loads and stores are younger, so everything is waited for)
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
@@ -937,15 +943,22 @@ __device__ __forceinline__ void ntp_run_tile(char* smem, unsigned lds0, int lane
         ntb_read<8192>(a[4], fa00); ntb_read<10240>(a[5], fa00); ntb_read<12288>(a[6], fa00); ntb_read<14336>(a[7], fa00);
     }
     int kt = 0;
-    for (; kt + 2 < nk; kt += 2) {
+    if (peel) {   // the first trip: K-tiles 0 and 1 (ticket request / publish), the accumulators written, not accumulated, by the first k-step
         int ticket;
-        NTP_FULL(0, kt, fa01, fb01, fa10, fb10, 1);
-        NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00, 1);
+        NTP_FULL(0, 0, fa01, fb01, fa10, fb10, 1, true);
+        NTP_FULL(1, 1, fa11, fb11, fa00, fb00, 1, false);
+        kt = 2;
+    }
+    for (; kt + 2 < nk; kt += 2) {
+        int ticket = 0;   // kt >= 2: no ticket traffic
+        NTP_FULL(0, kt, fa01, fb01, fa10, fb10, 0, false);
+        NTP_FULL(1, kt + 1, fa11, fb11, fa00, fb00, 0, false);
+        (void)ticket;
     }
     const bool two_left = kt + 1 < nk;
     if (two_left) {
-        int ticket = 0;   // kt > 0 here: no ticket traffic in this K-tile
-        NTP_FULL(0, kt, fa01, fb01, fa10, fb10, 0);
+        int ticket = 0;   // no ticket traffic in this K-tile (tickets need nk >= 3, and then kt >= 2 here)
+        NTP_FULL(0, kt, fa01, fb01, fa10, fb10, 0, false);
         (void)ticket;
     }
     // last K-tile: sub-step 0 under the reads of sub-step 1; then every read of both stages has retired on every wave (barrier),
