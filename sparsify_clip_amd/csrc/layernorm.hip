@@ -303,13 +303,20 @@ extern "C" int sc_layernorm_fwd(const float* x, int64_t rows, int64_t width, con
     // follow the actual width instead of the 2048-column maximum; narrow rows take 4 rows per wave
     const int ch = width <= 512 ? 2 : width <= 768 ? 3 : width <= 1024 ? 4 : 8;
     const bool multi = ch <= 4;
-    const dim3 grid((unsigned)sc_cdiv(rows, multi ? 16 : 4));
+    // rows per wave: 1 (rounds 1-2 took 4 for widths <= 1024 - more loads in flight per wave, but 64 data registers at width 1024 and fewer
+    // waves per SIMD; measured forward, 4 / 2 / 1 rows per wave: 48.9 / 42.3 / 37.8 us at [51200 x 768], 204.3 / 158.8 / 152.1 us at
+    // [131584 x 1024], profiles/r03_layernorm_times_v2.txt); SC_LN_FWD_RPW (debug builds) selects 4 or 2 for A/B runs
+    static const int rpw_env = [] { const char* e = sc_debug_env("SC_LN_FWD_RPW"); return e ? atoi(e) : 1; }();
+    const int rpw = multi && (rpw_env == 4 || rpw_env == 2) ? rpw_env : 1;
+    const dim3 grid((unsigned)sc_cdiv(rows, 4 * rpw));
     hipStream_t st = (hipStream_t)stream;
     if (dtype != SC_BF16 && dtype != SC_F32) return sc_set_error(SC_ERR_DTYPE, "sc_layernorm_fwd: bad dtype %d", dtype);
 #define LN_FWD(T, R, C) hipLaunchKernelGGL((layernorm_fwd_kernel<T, R, C>), grid, dim3(256), 0, st, x, rows, (int)width, gamma, beta, (T*)y, mean, rstd)
-#define LN_FWD_T(T) do { if (ch == 2) LN_FWD(T, 4, 2); else if (ch == 3) LN_FWD(T, 4, 3); else if (ch == 4) LN_FWD(T, 4, 4); else LN_FWD(T, 1, 8); } while (0)
+#define LN_FWD_R(T, C) do { if (rpw == 4) LN_FWD(T, 4, C); else if (rpw == 2) LN_FWD(T, 2, C); else LN_FWD(T, 1, C); } while (0)
+#define LN_FWD_T(T) do { if (ch == 2) LN_FWD_R(T, 2); else if (ch == 3) LN_FWD_R(T, 3); else if (ch == 4) LN_FWD_R(T, 4); else LN_FWD(T, 1, 8); } while (0)
     if (dtype == SC_BF16) LN_FWD_T(bf16_t); else LN_FWD_T(float);
 #undef LN_FWD_T
+#undef LN_FWD_R
 #undef LN_FWD
     SC_CHECK_LAUNCH();
     return SC_OK;
