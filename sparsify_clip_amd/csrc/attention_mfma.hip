@@ -20,7 +20,7 @@ using namespace attn;
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total_heads, float scale) {
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void attn_fwd_mfma_kernel(const bf16_t* qkv, bf16_t* out, int S, int W, int H, int total_heads, float scale) {
     constexpr int KS = (NT + 1) / 2;
     constexpr bool ODD = (NT & 1) != 0;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds_fwd[];
@@ -49,8 +49,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
             Vf[dt][s] = (ODD && s == KS - 1) ? tr_frag<false>(Vs, s, 16 * dt, lane) : tr_frag<true>(Vs, s, 16 * dt, lane);
 
     const int n_it = (S + 15) >> 4;
+    const float c = scale * 1.4426950408889634f;   // exp(x scale) = 2^(x c)
+    // the next query tile's fragments are requested under this tile's arithmetic (a tile used to start with a round trip to global memory:
+    // four or five per head, most of a head's time); unscaled scores (the maximum commutes with the positive scale), P = 2^((s - max) c) by
+    // one fma and one v_exp, compare / select on the tiles that hold masked pairs only (the last key tile, the causal diagonal)
+    bf16x8 q0 = row_frag_global(qb, ld, 0, 0, lane, S), q1 = row_frag_global(qb, ld, 0, 1, lane, S);
     for (int it = 0; it < n_it; ++it) {
-        const bf16x8 q0 = row_frag_global(qb, ld, it, 0, lane, S), q1 = row_frag_global(qb, ld, it, 1, lane, S);
+        bf16x8 nq0 = q0, nq1 = q1;
+        if (it + 1 < n_it) { nq0 = row_frag_global(qb, ld, it + 1, 0, lane, S); nq1 = row_frag_global(qb, ld, it + 1, 1, lane, S); }
         const int i = it * 16 + c16;
         f32x4 sc[NT + 1];
         float m = -INFINITY;
@@ -59,23 +65,25 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
             a = MFMA16(Kf[jt][0], q0, a);
             a = MFMA16(Kf[jt][1], q1, a);
+            if (jt * 16 + 16 > S || (CAUSAL && jt >= it)) {   // wave-uniform: tiles with masked pairs (under the causal mask also the tiles past the diagonal)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = jt * 16 + 4 * g + r;
-                const bool ok = j < S && (!CAUSAL || j <= i);
-                a[r] = ok ? a[r] * scale : -INFINITY;
-                m = fmaxf(m, a[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + 4 * g + r;
+                    a[r] = (j < S && (!CAUSAL || j <= i)) ? a[r] : -INFINITY;
+                }
             }
+            m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
             sc[jt] = a;
         }
         sc[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
         m = group_max(m);
+        const float nmc = -m * c;
         float l = 0.f;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[jt][r] - m);   // exp(-inf) = 0 for masked keys
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[jt][r], c, nmc));   // 2^(-inf) = 0 for masked keys
                 sc[jt][r] = p;
                 l += p;
             }
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* qkv, b
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) io<bf16_t>::st4(op + 16 * dt, o[dt] * inv);
         }
+        q0 = nq0; q1 = nq1;
     }
 }
 
